@@ -1,0 +1,236 @@
+/* C ABI of the MI355X path-tracing core (librt_hip.so).
+ *
+ * This is the seam at which the reference application's Vulkan back end is replaced: each entry
+ * point names the reference interface it stands in for (paths relative to the reference checkout).
+ * The reference keeps its renderer behind one facade type, `VulkanRenderer` (src/vulkan/mod.rs:1-15,
+ * src/vulkan/renderer.rs:62-507), fed by `Scene` (src/scene/mod.rs:67-205); a Rust `HipRenderer`
+ * binding these symbols is a drop-in for that facade's headless subset.
+ *
+ * Conventions
+ *   - every function returns RT_OK (0) or a negative rt_status; nothing throws or aborts across the ABI;
+ *   - rt_last_error(ctx) returns a NUL-terminated UTF-8 message owned by the context
+ *     (rt_last_error(NULL) returns the message of the last failed context-less call on this thread);
+ *   - the caller owns every host pointer; the library copies during the call;
+ *   - a context is bound to one GPU and must be used from one thread at a time
+ *     (the reference confines its renderer to one "render-thread", src/app/render_controller.rs:24-34);
+ *   - plain pointers and sizes only: no C++, HIP or PyTorch types.
+ */
+#ifndef RT_API_H
+#define RT_API_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "rt_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rt_status {
+    RT_OK               = 0,
+    RT_ERR_INVALID      = -1,   /* bad argument (NULL, zero size, inconsistent counts)              */
+    RT_ERR_DEVICE       = -2,   /* HIP runtime error; message carries hipGetErrorString             */
+    RT_ERR_NO_SCENE     = -3,   /* render/trace called before rt_upload_scene                        */
+    RT_ERR_UNSUPPORTED  = -4,   /* input honours the wire format but exceeds a documented limit      */
+    RT_ERR_OOM          = -5
+} rt_status;
+
+/* Behaviour switches. The defaults (flags = 0) give the *intended* semantics of the reference
+ * shader with an fp32 HDR accumulator; the RT_REF_* switches reproduce upstream defects bit-for-bit
+ * where a caller wants the legacy picture. */
+enum {
+    RT_REF_RGBA8_ACCUM   = 1u << 0, /* running mean stored in 8-bit UNORM per frame (main.comp:64,262-266)        */
+    RT_REF_CDF_PAD       = 1u << 1, /* light CDF length = 16-byte padded length (disney.comp:272, mod.rs:145-148) */
+    RT_FIX_ABSORPTION    = 1u << 2, /* Beer-Lambert with the physical sign instead of main.comp:182-184           */
+    RT_COUNT_TRAVERSAL   = 1u << 3, /* count node pops / triangle tests (mesh_tests, intersects.comp:136,140)     */
+    RT_KERNEL_TIMING     = 1u << 4, /* bracket every kernel launch with events (gpu_timer.rs:18-78 analogue)      */
+    RT_POP_CULL          = 1u << 5  /* drop a stacked subtree whose entry distance no longer beats the hit; may
+                                       change the winner among hits whose distances tie within rounding          */
+};
+
+typedef struct rt_config {
+    int32_t  device;          /* HIP device ordinal                                                  */
+    uint32_t width, height;   /* render resolution (VulkanRenderer::render_resolution)               */
+    uint32_t max_bounces;     /* BOUNCES in main.comp:4 (24 upstream); 0 selects 24                  */
+    uint32_t flags;           /* RT_* switches above                                                 */
+    uint32_t frames_per_pass; /* samples traced concurrently by one wavefront pass; 0 = automatic.
+                                 Forced to 1 when RT_REF_RGBA8_ACCUM is set.                         */
+} rt_config;
+
+typedef struct rt_ctx rt_ctx;
+
+/* Per-kernel device time of the last rt_render / rt_trace_* call, valid when RT_KERNEL_TIMING is set.
+ * Stands in for VulkanRenderer::last_timer_perf (renderer.rs:239-248). */
+typedef struct rt_timings {
+    float    total_ms;        /* whole call, first launch to last                      */
+    float    raygen_ms, extend_ms, shade_ms, connect_ms, accumulate_ms;
+    uint32_t raygen_launches, extend_launches, shade_launches, connect_launches, accumulate_launches;
+} rt_timings;
+
+/* Work counters since the last rt_reset_counters. node_pops / tri_tests stay 0 without RT_COUNT_TRAVERSAL. */
+typedef struct rt_counters {
+    uint64_t camera_rays;       /* paths started                                         */
+    uint64_t extend_rays;       /* closest-hit rays traced (camera + bounce rays)        */
+    uint64_t shadow_rays;       /* NEE visibility rays traced                            */
+    uint64_t extend_node_pops;  /* interior nodes popped by extend                       */
+    uint64_t extend_tri_tests;  /* triangles tested by extend                            */
+    uint64_t shadow_node_pops;
+    uint64_t shadow_tri_tests;
+    uint64_t extend_leaf_pops;
+    uint64_t shadow_leaf_pops;
+} rt_counters;
+
+/* 16-byte closest-hit record written by the extend stage. prim = 0xFFFFFFFF on a miss. */
+typedef struct rt_hit {
+    float    t, u, v;
+    uint32_t prim;
+} rt_hit;
+
+typedef struct rt_bvh_params {
+    float    traversal_cost;  /* 1.0 */
+    float    intersect_cost;  /* 1.0 */
+    uint32_t min_leaf;        /* 2   */
+    uint32_t max_leaf;        /* 8   */
+    uint32_t threads;         /* 0 = all hardware threads */
+} rt_bvh_params;
+
+typedef struct rt_bvh_stats {
+    float    sah_cost;
+    uint32_t node_count, leaf_count, max_depth, max_leaf_size;
+    float    avg_leaf_size;
+    float    build_ms;
+} rt_bvh_stats;
+
+/* ------------------------------------------------------------------------------------------------
+ * Host-side scene preparation (no GPU needed).
+ * ---------------------------------------------------------------------------------------------- */
+
+const char* rt_version(void);
+const char* rt_last_error(const rt_ctx* ctx);
+
+/* Binned-SAH object-split BVH over `n_tri` triangles, honouring the traversal contract of
+ * src/accelerators/bvh_based/bin_sah.rs:39-44 (what Scene::build_bvh, src/scene/mod.rs:84-115, produces
+ * with SplitPolicy::Object). `tris` is permuted in place into leaf order; `nodes` must have room for
+ * max(1, 2*n_tri-1) records. NULL params selects BinSah::default() (bin_sah.rs:115-125). */
+int rt_bvh_build(rt_triangle* tris, uint32_t n_tri, const rt_bvh_params* params,
+                 rt_bvh_node* nodes, uint32_t* n_nodes, rt_bvh_stats* stats);
+
+/* Emissive-triangle table and un-normalised power CDF, as Scene::build_lights (src/scene/mod.rs:207-270).
+ * `emissive` and `cdf` need room for n_tri entries. Call after rt_bvh_build (tri_index refers to leaf order). */
+int rt_build_lights(const rt_triangle* tris, uint32_t n_tri, const rt_material* mats, uint32_t n_mat,
+                    rt_emissive_tri* emissive, float* cdf, uint32_t* n_emissive, float* total_power);
+
+/* Section sizes (each rounded up to 16 bytes) of the packed scene blob
+ * [bvh | materials | triangles | lights | emissive | cdf] — Scene::get_buffer_sizes (src/scene/mod.rs:117-157). */
+int rt_scene_buffer_sizes(uint32_t n_bvh, uint32_t n_mat, uint32_t n_tri, uint32_t n_light,
+                          uint32_t n_emissive, uint64_t sizes[6]);
+
+/* Packs the six sections into `blob` (capacity >= sum of sizes) — Scene::write_buffers (src/scene/mod.rs:166-195). */
+int rt_scene_write_buffers(const rt_bvh_node* nodes, uint32_t n_bvh, const rt_material* mats, uint32_t n_mat,
+                           const rt_triangle* tris, uint32_t n_tri, const rt_light* lights, uint32_t n_light,
+                           const rt_emissive_tri* emissive, const float* cdf, uint32_t n_emissive,
+                           void* blob, uint64_t blob_capacity);
+
+/* Fills a camera block from a look-at pose exactly like the reference's YAML camera
+ * (src/types/camera_buffer_obj.rs:26-33,150-170): rotation = transpose(look_at_rh(location, look_at, +Y)). */
+int rt_camera_look_at(rt_camera* cam, uint32_t width, uint32_t height, const float location[3],
+                      const float look_at[3], float focal_length, float focus_distance, float aperture_radius);
+
+/* ------------------------------------------------------------------------------------------------
+ * Renderer (one context per GPU).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* VulkanRenderer::create (renderer.rs:62-120) + PathTracer::new (path_tracer/mod.rs:56-137), headless. */
+int  rt_create(const rt_config* cfg, rt_ctx** out);
+/* VulkanRenderer::destroy (renderer.rs:493-507). */
+void rt_destroy(rt_ctx* ctx);
+
+/* VulkanRenderer::upload_scene / reload_scene (renderer.rs:122-131,193-231) -> PathTracer::upload_scene
+ * (path_tracer/mod.rs:275-288). `blob`/`sizes` are what write_buffers / get_buffer_sizes produce; the counts are
+ * the true element counts (the shader derives them from padded byte ranges, which is how the upstream CDF-length
+ * defect arises). Re-lays the data out for the GPU and resets accumulation. */
+int rt_upload_scene(rt_ctx* ctx, const void* blob, const uint64_t sizes[6],
+                    uint32_t n_bvh, uint32_t n_mat, uint32_t n_tri, uint32_t n_light, uint32_t n_emissive);
+
+/* Texture array + cube map upload (path_tracer/mod.rs:99-137). All images are RGBA8 holding sRGB-encoded values,
+ * sampled bilinearly with one mip level; 2-D textures REPEAT, the cube clamps to the face edge
+ * (src/vulkan/core/image.rs:307-318, sampler.rs:10-34). skybox == NULL keeps/installs the 1x1 white cube
+ * (src/scene/mod.rs:49-65). */
+int rt_upload_textures(rt_ctx* ctx, const rt_texture* textures, uint32_t n_textures, const rt_texture* skybox);
+
+/* update_uniform_buffer (renderer.rs:465-475) + set_camera_pose (renderer.rs:165-168): installs the camera block and
+ * restarts accumulation. `resolution`, `view_port_uv` and `frame` in the block are overwritten by the context. */
+int rt_set_camera(rt_ctx* ctx, const rt_camera* cam);
+/* handle_resize (renderer.rs:133-162): new render resolution, restarts accumulation. */
+int rt_resize(rt_ctx* ctx, uint32_t width, uint32_t height);
+/* reset_accumulator (renderer.rs:170-177): frame counter back to 0, accumulator cleared. */
+int rt_reset_accumulation(rt_ctx* ctx);
+
+/* Multi-GPU sample slicing: this context renders global frame indices first, first+stride, first+2*stride, ...
+ * The per-pixel seed uses the global index (main.comp:251), so the union over all slices equals a 1-GPU run.
+ * Restarts accumulation. Default (0,1). No counterpart upstream (single GPU). */
+int rt_set_frame_slice(rt_ctx* ctx, uint32_t first, uint32_t stride);
+
+/* n_samples x dispatch_compute (renderer.rs:269-321): each sample is one full path per pixel with the frame index
+ * of its dispatch. Asynchronous: returns once the work is queued on the context's stream. */
+int rt_render(rt_ctx* ctx, uint32_t n_samples);
+/* Blocks until all queued work of the context has finished (frame_complete, renderer.rs:251-267). */
+int rt_sync(rt_ctx* ctx);
+/* sample_count (renderer.rs:180-182): samples accumulated by this context since the last reset. */
+uint32_t rt_sample_count(const rt_ctx* ctx);
+
+/* HDR mean (sum / count) as width*height RGBA floats, alpha = 1. New capability (upstream accumulates in 8 bits). */
+int rt_read_accum_f32(rt_ctx* ctx, float* rgba, size_t n_floats);
+/* Raw fp32 sum buffer (RGBA, alpha = sample count) for external reduction / checkpointing. */
+int rt_read_sum_f32(rt_ctx* ctx, float* rgba, size_t n_floats);
+/* Adds `rgba_sum` (same layout as rt_read_sum_f32) into the context's sum buffer: the receive side of a host-staged
+ * multi-GPU reduce, and resume-from-checkpoint. */
+int rt_add_sum_f32(rt_ctx* ctx, const float* rgba_sum, size_t n_floats);
+/* Device address and byte size of the fp32 RGBA sum buffer, for in-place RCCL reduction by the caller. */
+int rt_accum_device_buffer(rt_ctx* ctx, void** device_ptr, size_t* n_bytes);
+/* Tone-mapped 8-bit image, RGBA order: the contents SaveFrame writes (main.comp:215-244,267;
+ * src/vulkan/utils/save_frame.rs:27-65). */
+int rt_read_framebuffer_rgba8(rt_ctx* ctx, uint8_t* rgba, size_t n_bytes);
+
+int rt_last_timings(const rt_ctx* ctx, rt_timings* out);
+int rt_get_counters(rt_ctx* ctx, rt_counters* out);
+int rt_reset_counters(rt_ctx* ctx);
+
+/* ------------------------------------------------------------------------------------------------
+ * Stage-level entry points: the same kernels rt_render launches, on caller-supplied inputs.
+ * They exist so each stage can be checked in isolation against a CPU evaluation of the reference shader.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* extend stage = hit_meshes(ray, false) (intersects.comp:124-175). origins/directions: n x 3 floats. */
+int rt_trace_closest(rt_ctx* ctx, uint32_t n, const float* origins, const float* directions, rt_hit* hits);
+/* connect stage = the shadow test of DirectLight (disney.comp:697-701): visible[i] = 0 when the closest hit along the
+ * ray is nearer than tmax[i] and its material has spec_trans <= 0.5, else 1. */
+int rt_trace_shadow(rt_ctx* ctx, uint32_t n, const float* origins, const float* directions, const float* tmax,
+                    uint8_t* visible);
+/* Device-resident variants for throughput measurement: rays already in HBM as float4 {o.xyz,_} / {d.xyz,_};
+ * repeats the launch `repeat` times and reports the mean kernel time in milliseconds. */
+int rt_bench_trace(rt_ctx* ctx, uint32_t n, const float* origins, const float* directions, int shadow,
+                   uint32_t repeat, float* ms_per_launch);
+
+/* raygen stage = seed rule + generate_ray (main.comp:251; generate_ray.comp:2-29) for every pixel of frame `frame`.
+ * origins/directions: width*height x 3 floats; seeds: RNG state after the 8 camera draws. */
+int rt_generate_rays(rt_ctx* ctx, uint32_t frame, float* origins, float* directions, uint32_t* seeds);
+
+/* DisneyEval (disney.comp:560-619) on n independent inputs. V, N, L: n x 3 floats (world space, N = face-forward normal);
+ * eta: n floats; out_f: n x 3; out_pdf: n. Material roughness is used as given (the caller applies the 0.001 clamp). */
+int rt_eval_bsdf(rt_ctx* ctx, uint32_t n, const rt_material* mats, const float* eta, const float* V, const float* N,
+                 const float* L, float* out_f, float* out_pdf);
+/* DisneySample (disney.comp:476-558) with explicit random numbers r1r2 (n x 2). out_L: n x 3 world-space. */
+int rt_sample_bsdf(rt_ctx* ctx, uint32_t n, const rt_material* mats, const float* eta, const float* V, const float* N,
+                   const float* r1r2, float* out_L, float* out_f, float* out_pdf);
+/* Bilinear sRGB fetch of texture `tex` (or the cube map when tex == 0xFFFFFFFF, with uvw = direction). uvw: n x 3. */
+int rt_sample_texture(rt_ctx* ctx, uint32_t tex, uint32_t n, const float* uvw, float* rgba);
+
+/* Per-pixel radiance of ONE sample (frame index `frame`), before firefly clamp and accumulation:
+ * ray_color (main.comp:122-213). Does not touch the accumulator. rgb: width*height x 3 floats. */
+int rt_render_radiance(rt_ctx* ctx, uint32_t frame, float* rgb);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_API_H */

@@ -1,0 +1,784 @@
+// Host runtime of the render core: context, device buffers, stream-ordered kernel sequencing and the C ABI.
+//
+// A context plays the part of the reference's PathTracer + VulkanRenderer pair
+// (src/vulkan/path_tracer/mod.rs:56-344, src/vulkan/renderer.rs:62-507) without a window: it owns the scene in
+// device layout, the path-state and queue buffers, the fp32 accumulator and one HIP stream on which every
+// kernel of a render call is queued back to back (no host synchronisation inside rt_render).
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rt_api.h"
+#include "rt_internal.h"
+#include "rt_kernels.h"
+
+using namespace rtdev;
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf() { release(); }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+    hipError_t ensure(size_t n) {
+        if (n <= bytes && p) return hipSuccess;
+        release();
+        if (n == 0) n = 16;
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+enum Stage { ST_RAYGEN = 0, ST_EXTEND, ST_SHADE, ST_CONNECT, ST_ACCUM, ST_COUNT };
+
+struct Span { int stage; hipEvent_t a, b; };
+
+}  // namespace
+
+struct rt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    uint32_t W = 0, H = 0, npix = 0;
+    uint32_t max_bounces = 24, flags = 0, fpp_cfg = 0, fpp = 1;
+    uint32_t local_frame = 0;                 // samples issued by this context since the last reset
+    uint32_t slice_first = 0, slice_stride = 1;
+    rt_camera cam{};
+    bool have_scene = false, have_camera = false;
+    int n_cu = 256;
+
+    // scene
+    DevBuf nodes, isect, shade, mats, lights, light_tris, cdf, texels, tex_table, sky, srgb;
+    SceneDev sd{};
+    // paths
+    DevBuf ray_o, ray_d, hit, thr, rad, q0, q1, sq_o, sq_d, sq_c, counts, stats, seeds;
+    uint32_t slot_cap = 0;
+    // output
+    DevBuf sum, accum8, fb, scratch;
+
+    // timing
+    std::vector<hipEvent_t> event_pool;
+    size_t events_used = 0;
+    std::vector<Span> spans;
+    hipEvent_t call_begin = nullptr, call_end = nullptr;
+    rt_timings last{};
+    bool timings_dirty = false;
+
+    PathDev pd() const { return PathDev{ray_o.as<float4>(), ray_d.as<float4>(), hit.as<float4>(), thr.as<float4>(), rad.as<float4>()}; }
+    ShadowQueue sq() const { return ShadowQueue{sq_o.as<float4>(), sq_d.as<float4>(), sq_c.as<float4>()}; }
+    uint32_t* q_count() const { return counts.as<uint32_t>(); }
+    uint32_t* sh_count() const { return counts.as<uint32_t>() + (kMaxBounces + 1); }
+    TraceStats* tstats() const { return stats.as<TraceStats>(); }
+};
+
+namespace rtint {
+void set_ctx_error(rt_ctx* ctx, const std::string& msg) { ctx->err = msg; }
+}
+using rtint::fail;
+
+#define HIPCHK(ctx, call)                                                                                   \
+    do {                                                                                                    \
+        hipError_t e__ = (call);                                                                            \
+        if (e__ != hipSuccess)                                                                              \
+            return fail(ctx, e__ == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_DEVICE,                       \
+                        std::string(#call) + ": " + hipGetErrorString(e__));                                \
+    } while (0)
+
+namespace {
+
+uint32_t grid_for(const rt_ctx* c, uint64_t n, uint32_t blocks_per_cu) {
+    uint64_t need = (n + kBlock - 1) / kBlock;
+    uint64_t cap = uint64_t(c->n_cu) * blocks_per_cu;
+    return uint32_t(std::max<uint64_t>(1, std::min(need, cap)));
+}
+
+int bind_device(rt_ctx* c) { HIPCHK(c, hipSetDevice(c->device)); return RT_OK; }
+
+hipEvent_t take_event(rt_ctx* c) {
+    if (c->events_used == c->event_pool.size()) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        c->event_pool.push_back(e);
+    }
+    return c->event_pool[c->events_used++];
+}
+
+struct StageTimer {  // brackets one launch with events when kernel timing is on
+    rt_ctx* c; Span s{}; bool on;
+    StageTimer(rt_ctx* ctx, int stage) : c(ctx), on((ctx->flags & RT_KERNEL_TIMING) != 0) {
+        if (!on) return;
+        s.stage = stage; s.a = take_event(c); s.b = take_event(c);
+        if (!s.a || !s.b) { on = false; return; }
+        (void)hipEventRecord(s.a, c->stream);
+    }
+    ~StageTimer() {
+        if (!on) return;
+        (void)hipEventRecord(s.b, c->stream);
+        c->spans.push_back(s);
+    }
+};
+
+void begin_call(rt_ctx* c) {
+    c->events_used = 0;
+    c->spans.clear();
+    if (c->flags & RT_KERNEL_TIMING) {
+        if (!c->call_begin) (void)hipEventCreate(&c->call_begin);
+        if (!c->call_end) (void)hipEventCreate(&c->call_end);
+        (void)hipEventRecord(c->call_begin, c->stream);
+    }
+}
+void end_call(rt_ctx* c) {
+    if (c->flags & RT_KERNEL_TIMING) { (void)hipEventRecord(c->call_end, c->stream); c->timings_dirty = true; }
+}
+
+int resolve_timings(rt_ctx* c) {
+    if (!c->timings_dirty) return RT_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    rt_timings t{};
+    (void)hipEventElapsedTime(&t.total_ms, c->call_begin, c->call_end);
+    for (const Span& s : c->spans) {
+        float ms = 0.0f;
+        (void)hipEventElapsedTime(&ms, s.a, s.b);
+        switch (s.stage) {
+            case ST_RAYGEN: t.raygen_ms += ms; t.raygen_launches++; break;
+            case ST_EXTEND: t.extend_ms += ms; t.extend_launches++; break;
+            case ST_SHADE: t.shade_ms += ms; t.shade_launches++; break;
+            case ST_CONNECT: t.connect_ms += ms; t.connect_launches++; break;
+            default: t.accumulate_ms += ms; t.accumulate_launches++; break;
+        }
+    }
+    c->last = t;
+    c->timings_dirty = false;
+    return RT_OK;
+}
+
+int alloc_paths(rt_ctx* c) {
+    uint32_t fpp = c->fpp_cfg;
+    if (c->flags & RT_REF_RGBA8_ACCUM) fpp = 1;
+    if (fpp == 0) {
+        const uint64_t target = 4ull << 20;  // ~4 M paths in flight keep every CU fed through the late, sparse bounces
+        fpp = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(64, target / std::max<uint32_t>(1, c->npix))));
+    }
+    c->fpp = fpp;
+    uint64_t slots = uint64_t(fpp) * c->npix;
+    if (slots > 0xFFFFFFF0ull) return fail(c, RT_ERR_UNSUPPORTED, "resolution x frames_per_pass exceeds 2^32 path slots");
+    c->slot_cap = uint32_t(slots);
+    size_t v4 = size_t(slots) * sizeof(float4);
+    HIPCHK(c, c->ray_o.ensure(v4)); HIPCHK(c, c->ray_d.ensure(v4)); HIPCHK(c, c->hit.ensure(v4));
+    HIPCHK(c, c->thr.ensure(v4));   HIPCHK(c, c->rad.ensure(v4));
+    HIPCHK(c, c->q0.ensure(size_t(slots) * 4)); HIPCHK(c, c->q1.ensure(size_t(slots) * 4));
+    HIPCHK(c, c->sq_o.ensure(v4)); HIPCHK(c, c->sq_d.ensure(v4)); HIPCHK(c, c->sq_c.ensure(v4));
+    HIPCHK(c, c->seeds.ensure(size_t(c->npix) * 4));
+    HIPCHK(c, c->sum.ensure(size_t(c->npix) * sizeof(float4)));
+    HIPCHK(c, c->accum8.ensure(size_t(c->npix) * 4));
+    HIPCHK(c, c->fb.ensure(size_t(c->npix) * 4));
+    return RT_OK;
+}
+
+int clear_accum(rt_ctx* c) {
+    HIPCHK(c, hipMemsetAsync(c->sum.p, 0, size_t(c->npix) * sizeof(float4), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->accum8.p, 0, size_t(c->npix) * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->fb.p, 0, size_t(c->npix) * 4, c->stream));
+    c->local_frame = 0;
+    return RT_OK;
+}
+
+void refresh_camera(rt_ctx* c) {
+    c->cam.resolution[0] = c->W;
+    c->cam.resolution[1] = c->H;
+    float ratio = float(c->W) / float(c->H);  // viewport_uv, camera_buffer_obj.rs:26-33
+    if (ratio > 1.0f) { c->cam.view_port_uv[0] = ratio; c->cam.view_port_uv[1] = 1.0f; }
+    else { c->cam.view_port_uv[0] = 1.0f; c->cam.view_port_uv[1] = 1.0f / ratio; }
+    c->cam.frame = 0;
+}
+
+// One wavefront pass: `frames` samples of every pixel, bounce by bounce. Leaves radiance in pd.rad.
+int run_pass(rt_ctx* c, uint32_t frames, uint32_t frame_first, uint32_t frame_stride, uint32_t* seeds_out) {
+    const uint32_t n_slots = frames * c->npix;
+    const bool count = (c->flags & RT_COUNT_TRAVERSAL) != 0;
+    PathDev pd = c->pd();
+    ShadowQueue sq = c->sq();
+    {
+        StageTimer tm(c, ST_RAYGEN);
+        hipLaunchKernelGGL(k_raygen, dim3(grid_for(c, n_slots, 8)), dim3(kBlock), 0, c->stream, c->cam, pd, c->npix, n_slots,
+                           frame_first, frame_stride, seeds_out);
+    }
+    uint32_t* queues[2] = {c->q0.as<uint32_t>(), c->q1.as<uint32_t>()};
+    const uint32_t trace_grid = grid_for(c, n_slots, 6);
+    const uint32_t shade_grid = grid_for(c, n_slots, 4);
+    for (uint32_t b = 0; b < c->max_bounces; ++b) {
+        const uint32_t* in_q = b == 0 ? nullptr : queues[b & 1];
+        const uint32_t* in_n = b == 0 ? nullptr : c->q_count() + b;
+        {
+            StageTimer tm(c, ST_EXTEND);
+            if (count) hipLaunchKernelGGL(k_extend<true>, dim3(trace_grid), dim3(kBlock), 0, c->stream, c->sd, pd, in_q, in_n, n_slots, c->tstats());
+            else hipLaunchKernelGGL(k_extend<false>, dim3(trace_grid), dim3(kBlock), 0, c->stream, c->sd, pd, in_q, in_n, n_slots, c->tstats());
+        }
+        {
+            StageTimer tm(c, ST_SHADE);
+            ShadeParams sp{b, c->max_bounces, c->flags, in_q, in_n, n_slots, queues[(b + 1) & 1], c->q_count() + b + 1, c->sh_count() + b};
+            hipLaunchKernelGGL(k_shade, dim3(shade_grid), dim3(kBlock), 0, c->stream, c->sd, pd, sq, sp);
+        }
+        if (c->sd.n_light + c->sd.n_emissive != 0) {
+            StageTimer tm(c, ST_CONNECT);
+            if (count) hipLaunchKernelGGL(k_connect<true>, dim3(trace_grid), dim3(kBlock), 0, c->stream, c->sd, pd, sq, c->sh_count() + b, c->tstats());
+            else hipLaunchKernelGGL(k_connect<false>, dim3(trace_grid), dim3(kBlock), 0, c->stream, c->sd, pd, sq, c->sh_count() + b, c->tstats());
+        }
+    }
+    HIPCHK(c, hipGetLastError());
+    return RT_OK;
+}
+
+int finish_pass(rt_ctx* c, uint32_t n_slots) {
+    hipLaunchKernelGGL(k_finish_pass, dim3(1), dim3(64), 0, c->stream, c->q_count(), c->sh_count(), kMaxBounces + 1, n_slots, c->tstats());
+    HIPCHK(c, hipGetLastError());
+    return RT_OK;
+}
+
+int ready_to_render(rt_ctx* c) {
+    if (!c->have_scene) return fail(c, RT_ERR_NO_SCENE, "no scene uploaded");
+    if (!c->have_camera) return fail(c, RT_ERR_NO_SCENE, "no camera set");
+    return RT_OK;
+}
+
+// n x 3 floats on the host -> n float4 on the device (w from `w`, or 0).
+int upload_vec3(rt_ctx* c, DevBuf& buf, uint32_t n, const float* xyz3, const float* w) {
+    std::vector<float> tmp(size_t(n) * 4);
+    for (uint32_t i = 0; i < n; ++i) {
+        tmp[4 * i] = xyz3[3 * i]; tmp[4 * i + 1] = xyz3[3 * i + 1]; tmp[4 * i + 2] = xyz3[3 * i + 2];
+        tmp[4 * i + 3] = w ? w[i] : 0.0f;
+    }
+    HIPCHK(c, buf.ensure(tmp.size() * 4));
+    HIPCHK(c, hipMemcpyAsync(buf.p, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+}  // namespace
+
+// =====================================================================================================
+
+extern "C" const char* rt_last_error(const rt_ctx* ctx) { return ctx ? ctx->err.c_str() : rtint::thread_error(); }
+
+extern "C" int rt_create(const rt_config* cfg, rt_ctx** out) {
+    if (!cfg || !out) return fail(nullptr, RT_ERR_INVALID, "rt_create: null argument");
+    if (cfg->width == 0 || cfg->height == 0) return fail(nullptr, RT_ERR_INVALID, "rt_create: zero resolution");
+    uint32_t mb = cfg->max_bounces ? cfg->max_bounces : 24;
+    if (mb > kMaxBounces) return fail(nullptr, RT_ERR_UNSUPPORTED, "rt_create: max_bounces above 64");
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev == 0)
+        return fail(nullptr, RT_ERR_DEVICE, std::string("rt_create: no HIP device available (") + hipGetErrorString(e) + ")");
+    if (cfg->device < 0 || cfg->device >= n_dev) return fail(nullptr, RT_ERR_INVALID, "rt_create: device ordinal out of range");
+    rt_ctx* c = new rt_ctx;
+    c->device = cfg->device;
+    c->W = cfg->width; c->H = cfg->height; c->npix = cfg->width * cfg->height;
+    c->max_bounces = mb; c->flags = cfg->flags; c->fpp_cfg = cfg->frames_per_pass;
+    auto bail = [&](int code) { std::string m = c->err; rt_destroy(c); fail(nullptr, code, m); return code; };
+    if (uint64_t(cfg->width) * cfg->height > 0x7FFFFFFFull) { c->err = "resolution too large"; return bail(RT_ERR_UNSUPPORTED); }
+    int rc;
+    if ((rc = bind_device(c)) != RT_OK) return bail(rc);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) c->n_cu = std::max(1, prop.multiProcessorCount);
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return bail(RT_ERR_DEVICE); }
+    if ((rc = alloc_paths(c)) != RT_OK) return bail(rc);
+    if (c->counts.ensure(sizeof(uint32_t) * 2 * (kMaxBounces + 1)) != hipSuccess || c->stats.ensure(sizeof(TraceStats)) != hipSuccess) {
+        c->err = "counter allocation failed"; return bail(RT_ERR_OOM);
+    }
+    (void)hipMemsetAsync(c->counts.p, 0, c->counts.bytes, c->stream);
+    (void)hipMemsetAsync(c->stats.p, 0, c->stats.bytes, c->stream);
+    // sRGB decode table, identical to what a CPU evaluation computes: exact curve in double, rounded once
+    float lut[256];
+    for (int i = 0; i < 256; ++i) {
+        double v = i / 255.0;
+        lut[i] = float(v <= 0.04045 ? v / 12.92 : std::pow((v + 0.055) / 1.055, 2.4));
+    }
+    if (c->srgb.ensure(sizeof(lut)) != hipSuccess || hipMemcpy(c->srgb.p, lut, sizeof(lut), hipMemcpyHostToDevice) != hipSuccess) {
+        c->err = "sRGB table upload failed"; return bail(RT_ERR_DEVICE);
+    }
+    if ((rc = rt_upload_textures(c, nullptr, 0, nullptr)) != RT_OK) return bail(rc);
+    if ((rc = clear_accum(c)) != RT_OK) return bail(rc);
+    if (hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "stream sync failed"; return bail(RT_ERR_DEVICE); }
+    *out = c;
+    return RT_OK;
+}
+
+extern "C" void rt_destroy(rt_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+    if (c->call_begin) (void)hipEventDestroy(c->call_begin);
+    if (c->call_end) (void)hipEventDestroy(c->call_end);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int rt_upload_scene(rt_ctx* c, const void* blob, const uint64_t sizes[6], uint32_t n_bvh, uint32_t n_mat,
+                               uint32_t n_tri, uint32_t n_light, uint32_t n_emissive) {
+    if (!c) return RT_ERR_INVALID;
+    if (!blob || !sizes) return fail(c, RT_ERR_INVALID, "rt_upload_scene: null argument");
+    uint64_t want[6];
+    rt_scene_buffer_sizes(n_bvh, n_mat, n_tri, n_light, n_emissive, want);
+    for (int s = 0; s < 6; ++s)
+        if (sizes[s] < want[s]) return fail(c, RT_ERR_INVALID, "rt_upload_scene: section " + std::to_string(s) + " smaller than its element count requires");
+    if (n_bvh == 0) return fail(c, RT_ERR_INVALID, "rt_upload_scene: a scene has at least the root node");
+    int rc;
+    if ((rc = bind_device(c)) != RT_OK) return rc;
+    const uint8_t* p = static_cast<const uint8_t*>(blob);
+    const rt_bvh_node* nodes = reinterpret_cast<const rt_bvh_node*>(p); p += sizes[0];
+    const rt_material* mats = reinterpret_cast<const rt_material*>(p); p += sizes[1];
+    const rt_triangle* tris = reinterpret_cast<const rt_triangle*>(p); p += sizes[2];
+    const rt_light* lights = reinterpret_cast<const rt_light*>(p); p += sizes[3];
+    const rt_emissive_tri* emis = reinterpret_cast<const rt_emissive_tri*>(p); p += sizes[4];
+    const float* cdf = reinterpret_cast<const float*>(p);
+
+    rtint::GpuScene gs;
+    std::string err;
+    rc = rtint::convert_scene(nodes, n_bvh, tris, n_tri, mats, n_mat, gs, err);
+    if (rc != RT_OK) return fail(c, rc, "rt_upload_scene: " + err);
+
+    // device light table: {v0, area} {v1, Le.r} {v2, Le.g} {unit normal, Le.b} per emissive triangle
+    std::vector<float> lt(size_t(n_emissive) * 16);
+    for (uint32_t i = 0; i < n_emissive; ++i) {
+        const rt_emissive_tri& e = emis[i];
+        if (e.tri_index >= n_tri) return fail(c, RT_ERR_INVALID, "rt_upload_scene: emissive entry references a missing triangle");
+        const rt_triangle& t = tris[e.tri_index];
+        const rt_material& m = mats[t.material_idx];
+        const rtint::TriIsect& q = gs.isect[e.tri_index];
+        float* o = &lt[size_t(i) * 16];
+        o[0] = t.v[0][0]; o[1] = t.v[0][1]; o[2] = t.v[0][2]; o[3] = e.area;
+        o[4] = t.v[1][0]; o[5] = t.v[1][1]; o[6] = t.v[1][2]; o[7] = m.emission[0];
+        o[8] = t.v[2][0]; o[9] = t.v[2][1]; o[10] = t.v[2][2]; o[11] = m.emission[1];
+        o[12] = q.a[3];   o[13] = q.b[3];   o[14] = q.c[3];    o[15] = m.emission[2];
+    }
+
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    auto put = [&](DevBuf& b, const void* src, size_t bytes) -> hipError_t {
+        hipError_t e = b.ensure(bytes);
+        if (e != hipSuccess) return e;
+        if (bytes) e = hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice);
+        return e;
+    };
+    HIPCHK(c, put(c->nodes, gs.nodes.data(), gs.nodes.size() * sizeof(rtint::NodePair)));
+    HIPCHK(c, put(c->isect, gs.isect.data(), gs.isect.size() * sizeof(rtint::TriIsect)));
+    HIPCHK(c, put(c->shade, gs.shade.data(), gs.shade.size() * sizeof(rtint::TriShade)));
+    HIPCHK(c, put(c->mats, mats, size_t(n_mat) * sizeof(rt_material)));
+    HIPCHK(c, put(c->lights, lights, size_t(n_light) * sizeof(rt_light)));
+    HIPCHK(c, put(c->light_tris, lt.data(), lt.size() * 4));
+    HIPCHK(c, put(c->cdf, cdf, size_t(n_emissive) * 4));
+
+    SceneDev& sd = c->sd;
+    sd.nodes = c->nodes.as<float4>(); sd.isect = c->isect.as<float4>(); sd.shade = c->shade.as<float4>();
+    sd.mats = c->mats.as<float4>(); sd.lights = c->lights.as<float4>(); sd.light_tris = c->light_tris.as<float4>();
+    sd.cdf = c->cdf.as<float>();
+    sd.root_ref = gs.root_ref; sd.n_tri = n_tri; sd.n_light = n_light; sd.n_emissive = n_emissive;
+    // The shader sizes the CDF from its 16-byte padded binding; an empty table is bound as one dummy word
+    // (src/vulkan/path_tracer/descriptors.rs:85-93).
+    uint32_t seen = n_emissive;
+    if (c->flags & RT_REF_CDF_PAD) seen = uint32_t(want[5] / 4);
+    sd.cdf_len_seen = std::max(1u, seen);
+    c->have_scene = true;
+    return clear_accum(c);
+}
+
+extern "C" int rt_upload_textures(rt_ctx* c, const rt_texture* textures, uint32_t n, const rt_texture* skybox) {
+    if (!c) return RT_ERR_INVALID;
+    if (n && !textures) return fail(c, RT_ERR_INVALID, "rt_upload_textures: null texture array");
+    int rc;
+    if ((rc = bind_device(c)) != RT_OK) return rc;
+    std::vector<uint32_t> table(size_t(std::max(1u, n)) * 4, 0u);
+    size_t total = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (!textures[i].pixels || textures[i].width == 0 || textures[i].height == 0)
+            return fail(c, RT_ERR_INVALID, "rt_upload_textures: empty texture " + std::to_string(i));
+        if (total + size_t(textures[i].width) * textures[i].height > 0xFFFFFFFFull)
+            return fail(c, RT_ERR_UNSUPPORTED, "rt_upload_textures: more than 2^32 texels in total");
+        table[4 * i] = uint32_t(total); table[4 * i + 1] = textures[i].width; table[4 * i + 2] = textures[i].height;
+        total += size_t(textures[i].width) * textures[i].height;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, c->texels.ensure(std::max<size_t>(16, total * 4)));
+    for (uint32_t i = 0; i < n; ++i)
+        HIPCHK(c, hipMemcpy(c->texels.as<uint32_t>() + table[4 * i], textures[i].pixels,
+                            size_t(textures[i].width) * textures[i].height * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, c->tex_table.ensure(table.size() * 4));
+    HIPCHK(c, hipMemcpy(c->tex_table.p, table.data(), table.size() * 4, hipMemcpyHostToDevice));
+    TexView& tv = c->sd.tex;
+    tv.texels = c->texels.as<uint32_t>(); tv.table = c->tex_table.as<uint4>(); tv.n_tex = n; tv.srgb = c->srgb.as<float>();
+    if (skybox) {
+        if (!skybox->pixels || skybox->width == 0 || skybox->height == 0) return fail(c, RT_ERR_INVALID, "rt_upload_textures: empty skybox");
+        size_t bytes = size_t(skybox->width) * skybox->height * 4 * 6;
+        HIPCHK(c, c->sky.ensure(bytes));
+        HIPCHK(c, hipMemcpy(c->sky.p, skybox->pixels, bytes, hipMemcpyHostToDevice));
+        tv.sky_w = skybox->width; tv.sky_h = skybox->height;
+    } else if (!c->sky.p) {
+        const uint32_t white[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        HIPCHK(c, c->sky.ensure(sizeof(white)));
+        HIPCHK(c, hipMemcpy(c->sky.p, white, sizeof(white), hipMemcpyHostToDevice));
+        tv.sky_w = tv.sky_h = 1;
+    }
+    tv.sky = c->sky.as<uint32_t>();
+    if (c->sum.p) return clear_accum(c);
+    return RT_OK;
+}
+
+extern "C" int rt_set_camera(rt_ctx* c, const rt_camera* cam) {
+    if (!c) return RT_ERR_INVALID;
+    if (!cam) return fail(c, RT_ERR_INVALID, "rt_set_camera: null camera");
+    if (!(cam->focal_length != 0.0f)) return fail(c, RT_ERR_INVALID, "rt_set_camera: focal_length is zero");
+    int rc;
+    if ((rc = bind_device(c)) != RT_OK) return rc;
+    c->cam = *cam;
+    refresh_camera(c);
+    c->have_camera = true;
+    return clear_accum(c);
+}
+
+extern "C" int rt_resize(rt_ctx* c, uint32_t w, uint32_t h) {
+    if (!c) return RT_ERR_INVALID;
+    if (w == 0 || h == 0 || uint64_t(w) * h > 0x7FFFFFFFull) return fail(c, RT_ERR_INVALID, "rt_resize: bad resolution");
+    int rc;
+    if ((rc = bind_device(c)) != RT_OK) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->W = w; c->H = h; c->npix = w * h;
+    if ((rc = alloc_paths(c)) != RT_OK) return rc;
+    refresh_camera(c);
+    return clear_accum(c);
+}
+
+extern "C" int rt_reset_accumulation(rt_ctx* c) {
+    if (!c) return RT_ERR_INVALID;
+    int rc;
+    if ((rc = bind_device(c)) != RT_OK) return rc;
+    return clear_accum(c);
+}
+
+extern "C" int rt_set_frame_slice(rt_ctx* c, uint32_t first, uint32_t stride) {
+    if (!c) return RT_ERR_INVALID;
+    if (stride == 0) return fail(c, RT_ERR_INVALID, "rt_set_frame_slice: stride is zero");
+    int rc;
+    if ((rc = bind_device(c)) != RT_OK) return rc;
+    c->slice_first = first; c->slice_stride = stride;
+    return clear_accum(c);
+}
+
+extern "C" int rt_render(rt_ctx* c, uint32_t n_samples) {
+    if (!c) return RT_ERR_INVALID;
+    int rc;
+    if ((rc = ready_to_render(c)) != RT_OK) return rc;
+    if ((rc = bind_device(c)) != RT_OK) return rc;
+    begin_call(c);
+    uint32_t left = n_samples;
+    while (left) {
+        uint32_t frames = std::min(left, c->fpp);
+        uint32_t frame_first = c->slice_first + c->local_frame * c->slice_stride;
+        if ((rc = run_pass(c, frames, frame_first, c->slice_stride, nullptr)) != RT_OK) return rc;
+        {
+            StageTimer tm(c, ST_ACCUM);
+            hipLaunchKernelGGL(k_accumulate, dim3(grid_for(c, c->npix, 8)), dim3(kBlock), 0, c->stream, c->pd(), c->sum.as<float4>(),
+                               c->accum8.as<uint32_t>(), c->fb.as<uint32_t>(), c->npix, frames, frame_first, c->slice_stride,
+                               (c->flags & RT_REF_RGBA8_ACCUM) ? 1u : 0u);
+        }
+        if ((rc = finish_pass(c, frames * c->npix)) != RT_OK) return rc;
+        c->local_frame += frames;
+        left -= frames;
+    }
+    end_call(c);
+    return RT_OK;
+}
+
+extern "C" int rt_sync(rt_ctx* c) {
+    if (!c) return RT_ERR_INVALID;
+    int rc;
+    if ((rc = bind_device(c)) != RT_OK) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+extern "C" uint32_t rt_sample_count(const rt_ctx* c) { return c ? c->local_frame : 0; }
+
+extern "C" int rt_read_sum_f32(rt_ctx* c, float* rgba, size_t n_floats) {
+    if (!c) return RT_ERR_INVALID;
+    if (!rgba || n_floats < size_t(c->npix) * 4) return fail(c, RT_ERR_INVALID, "rt_read_sum_f32: buffer too small");
+    int rc;
+    if ((rc = bind_device(c)) != RT_OK) return rc;
+    HIPCHK(c, hipMemcpyAsync(rgba, c->sum.p, size_t(c->npix) * 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+extern "C" int rt_read_accum_f32(rt_ctx* c, float* rgba, size_t n_floats) {
+    int rc = rt_read_sum_f32(c, rgba, n_floats);
+    if (rc != RT_OK) return rc;
+    if (c->flags & RT_REF_RGBA8_ACCUM) {  // the mean lives in the 8-bit image in legacy mode
+        std::vector<uint32_t> a8(c->npix);
+        HIPCHK(c, hipMemcpy(a8.data(), c->accum8.p, size_t(c->npix) * 4, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < c->npix; ++i)
+            for (int k = 0; k < 4; ++k) rgba[4 * size_t(i) + k] = float((a8[i] >> (8 * k)) & 255u) / 255.0f;
+        return RT_OK;
+    }
+    for (uint32_t i = 0; i < c->npix; ++i) {
+        float* p = rgba + 4 * size_t(i);
+        float n = p[3];
+        float inv = n > 0.0f ? 1.0f / n : 0.0f;
+        p[0] *= inv; p[1] *= inv; p[2] *= inv; p[3] = n > 0.0f ? 1.0f : 0.0f;
+    }
+    return RT_OK;
+}
+
+extern "C" int rt_add_sum_f32(rt_ctx* c, const float* rgba_sum, size_t n_floats) {
+    if (!c) return RT_ERR_INVALID;
+    if (!rgba_sum || n_floats < size_t(c->npix) * 4) return fail(c, RT_ERR_INVALID, "rt_add_sum_f32: buffer too small");
+    int rc;
+    if ((rc = bind_device(c)) != RT_OK) return rc;
+    HIPCHK(c, c->scratch.ensure(size_t(c->npix) * 16));
+    HIPCHK(c, hipMemcpyAsync(c->scratch.p, rgba_sum, size_t(c->npix) * 16, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_add_sum, dim3(grid_for(c, c->npix, 8)), dim3(kBlock), 0, c->stream, c->sum.as<float4>(), c->scratch.as<float4>(), c->npix);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+extern "C" int rt_accum_device_buffer(rt_ctx* c, void** device_ptr, size_t* n_bytes) {
+    if (!c) return RT_ERR_INVALID;
+    if (!device_ptr || !n_bytes) return fail(c, RT_ERR_INVALID, "rt_accum_device_buffer: null argument");
+    *device_ptr = c->sum.p;
+    *n_bytes = size_t(c->npix) * 16;
+    return RT_OK;
+}
+
+extern "C" int rt_read_framebuffer_rgba8(rt_ctx* c, uint8_t* rgba, size_t n_bytes) {
+    if (!c) return RT_ERR_INVALID;
+    if (!rgba || n_bytes < size_t(c->npix) * 4) return fail(c, RT_ERR_INVALID, "rt_read_framebuffer_rgba8: buffer too small");
+    int rc;
+    if ((rc = bind_device(c)) != RT_OK) return rc;
+    if (!(c->flags & RT_REF_RGBA8_ACCUM)) {
+        hipLaunchKernelGGL(k_tonemap, dim3(grid_for(c, c->npix, 8)), dim3(kBlock), 0, c->stream, c->sum.as<float4>(), c->fb.as<uint32_t>(), c->npix);
+        HIPCHK(c, hipGetLastError());
+    }
+    HIPCHK(c, hipMemcpyAsync(rgba, c->fb.p, size_t(c->npix) * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+extern "C" int rt_last_timings(const rt_ctx* cc, rt_timings* out) {
+    rt_ctx* c = const_cast<rt_ctx*>(cc);
+    if (!c) return RT_ERR_INVALID;
+    if (!out) return fail(c, RT_ERR_INVALID, "rt_last_timings: null output");
+    if (!(c->flags & RT_KERNEL_TIMING)) return fail(c, RT_ERR_INVALID, "rt_last_timings: context created without RT_KERNEL_TIMING");
+    int rc;
+    if ((rc = bind_device(c)) != RT_OK) return rc;
+    if ((rc = resolve_timings(c)) != RT_OK) return rc;
+    *out = c->last;
+    return RT_OK;
+}
+
+extern "C" int rt_get_counters(rt_ctx* c, rt_counters* out) {
+    if (!c) return RT_ERR_INVALID;
+    if (!out) return fail(c, RT_ERR_INVALID, "rt_get_counters: null output");
+    int rc;
+    if ((rc = bind_device(c)) != RT_OK) return rc;
+    TraceStats s;
+    HIPCHK(c, hipMemcpyAsync(&s, c->stats.p, sizeof(s), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    out->camera_rays = s.camera_rays; out->extend_rays = s.extend_rays; out->shadow_rays = s.shadow_rays;
+    out->extend_node_pops = s.extend_node_pops; out->extend_tri_tests = s.extend_tri_tests; out->extend_leaf_pops = s.extend_leaf_pops;
+    out->shadow_node_pops = s.shadow_node_pops; out->shadow_tri_tests = s.shadow_tri_tests; out->shadow_leaf_pops = s.shadow_leaf_pops;
+    return RT_OK;
+}
+
+extern "C" int rt_reset_counters(rt_ctx* c) {
+    if (!c) return RT_ERR_INVALID;
+    int rc;
+    if ((rc = bind_device(c)) != RT_OK) return rc;
+    HIPCHK(c, hipMemsetAsync(c->stats.p, 0, sizeof(TraceStats), c->stream));
+    return RT_OK;
+}
+
+// ---- stage-level entry points ---------------------------------------------------------------------------
+
+static int trace_common(rt_ctx* c, uint32_t n, const float* origins, const float* directions, const float* tmax, int shadow,
+                        std::vector<float>& host_hits) {
+    if (!c->have_scene) return fail(c, RT_ERR_NO_SCENE, "no scene uploaded");
+    int rc;
+    if ((rc = bind_device(c)) != RT_OK) return rc;
+    host_hits.assign(size_t(n) * 4, 0.0f);
+    if (n == 0) return RT_OK;
+    DevBuf ro, rd, hits;
+    if ((rc = upload_vec3(c, ro, n, origins, tmax)) != RT_OK) return rc;
+    if ((rc = upload_vec3(c, rd, n, directions, nullptr)) != RT_OK) return rc;
+    HIPCHK(c, hits.ensure(size_t(n) * 16));
+    const bool count = (c->flags & RT_COUNT_TRAVERSAL) != 0;
+    begin_call(c);
+    {
+        StageTimer tm(c, shadow ? ST_CONNECT : ST_EXTEND);
+        if (count) hipLaunchKernelGGL(k_trace_rays<true>, dim3(grid_for(c, n, 6)), dim3(kBlock), 0, c->stream, c->sd, ro.as<float4>(), rd.as<float4>(), n, shadow, hits.as<float4>(), c->tstats());
+        else hipLaunchKernelGGL(k_trace_rays<false>, dim3(grid_for(c, n, 6)), dim3(kBlock), 0, c->stream, c->sd, ro.as<float4>(), rd.as<float4>(), n, shadow, hits.as<float4>(), c->tstats());
+    }
+    end_call(c);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(host_hits.data(), hits.p, size_t(n) * 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+extern "C" int rt_trace_closest(rt_ctx* c, uint32_t n, const float* origins, const float* directions, rt_hit* hits) {
+    if (!c) return RT_ERR_INVALID;
+    if (n && (!origins || !directions || !hits)) return fail(c, RT_ERR_INVALID, "rt_trace_closest: null argument");
+    std::vector<float> h;
+    int rc = trace_common(c, n, origins, directions, nullptr, 0, h);
+    if (rc != RT_OK) return rc;
+    std::memcpy(hits, h.data(), size_t(n) * sizeof(rt_hit));
+    return RT_OK;
+}
+
+extern "C" int rt_trace_shadow(rt_ctx* c, uint32_t n, const float* origins, const float* directions, const float* tmax,
+                               uint8_t* visible) {
+    if (!c) return RT_ERR_INVALID;
+    if (n && (!origins || !directions || !tmax || !visible)) return fail(c, RT_ERR_INVALID, "rt_trace_shadow: null argument");
+    std::vector<float> h;
+    int rc = trace_common(c, n, origins, directions, tmax, 1, h);
+    if (rc != RT_OK) return rc;
+    for (uint32_t i = 0; i < n; ++i) visible[i] = h[4 * size_t(i)] != 0.0f ? 1 : 0;
+    return RT_OK;
+}
+
+extern "C" int rt_bench_trace(rt_ctx* c, uint32_t n, const float* origins, const float* directions, int shadow, uint32_t repeat,
+                              float* ms_per_launch) {
+    if (!c) return RT_ERR_INVALID;
+    if (!n || !origins || !directions || !ms_per_launch || !repeat) return fail(c, RT_ERR_INVALID, "rt_bench_trace: bad argument");
+    if (!c->have_scene) return fail(c, RT_ERR_NO_SCENE, "no scene uploaded");
+    int rc;
+    if ((rc = bind_device(c)) != RT_OK) return rc;
+    DevBuf ro, rd, hits;
+    std::vector<float> far_t(n, INFINITY);
+    if ((rc = upload_vec3(c, ro, n, origins, shadow ? far_t.data() : nullptr)) != RT_OK) return rc;
+    if ((rc = upload_vec3(c, rd, n, directions, nullptr)) != RT_OK) return rc;
+    HIPCHK(c, hits.ensure(size_t(n) * 16));
+    hipEvent_t a, b;
+    HIPCHK(c, hipEventCreate(&a));
+    HIPCHK(c, hipEventCreate(&b));
+    auto launch = [&] {
+        hipLaunchKernelGGL(k_trace_rays<false>, dim3(grid_for(c, n, 6)), dim3(kBlock), 0, c->stream, c->sd, ro.as<float4>(), rd.as<float4>(), n, shadow, hits.as<float4>(), c->tstats());
+    };
+    launch();  // warm-up
+    (void)hipEventRecord(a, c->stream);
+    for (uint32_t r = 0; r < repeat; ++r) launch();
+    (void)hipEventRecord(b, c->stream);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    float ms = 0.0f;
+    (void)hipEventElapsedTime(&ms, a, b);
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    HIPCHK(c, e);
+    HIPCHK(c, hipGetLastError());
+    *ms_per_launch = ms / float(repeat);
+    return RT_OK;
+}
+
+static int download_vec3(rt_ctx* c, const float4* dev, uint32_t n, float* out3) {
+    std::vector<float> tmp(size_t(n) * 4);
+    HIPCHK(c, hipMemcpyAsync(tmp.data(), dev, tmp.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (uint32_t i = 0; i < n; ++i) { out3[3 * size_t(i)] = tmp[4 * size_t(i)]; out3[3 * size_t(i) + 1] = tmp[4 * size_t(i) + 1]; out3[3 * size_t(i) + 2] = tmp[4 * size_t(i) + 2]; }
+    return RT_OK;
+}
+
+extern "C" int rt_generate_rays(rt_ctx* c, uint32_t frame, float* origins, float* directions, uint32_t* seeds) {
+    if (!c) return RT_ERR_INVALID;
+    if (!origins || !directions) return fail(c, RT_ERR_INVALID, "rt_generate_rays: null argument");
+    if (!c->have_camera) return fail(c, RT_ERR_NO_SCENE, "no camera set");
+    int rc;
+    if ((rc = bind_device(c)) != RT_OK) return rc;
+    hipLaunchKernelGGL(k_raygen, dim3(grid_for(c, c->npix, 8)), dim3(kBlock), 0, c->stream, c->cam, c->pd(), c->npix, c->npix, frame, 1u,
+                       c->seeds.as<uint32_t>());
+    HIPCHK(c, hipGetLastError());
+    if ((rc = download_vec3(c, c->ray_o.as<float4>(), c->npix, origins)) != RT_OK) return rc;
+    if ((rc = download_vec3(c, c->ray_d.as<float4>(), c->npix, directions)) != RT_OK) return rc;
+    if (seeds) HIPCHK(c, hipMemcpy(seeds, c->seeds.p, size_t(c->npix) * 4, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+extern "C" int rt_render_radiance(rt_ctx* c, uint32_t frame, float* rgb) {
+    if (!c) return RT_ERR_INVALID;
+    if (!rgb) return fail(c, RT_ERR_INVALID, "rt_render_radiance: null output");
+    int rc;
+    if ((rc = ready_to_render(c)) != RT_OK) return rc;
+    if ((rc = bind_device(c)) != RT_OK) return rc;
+    begin_call(c);
+    if ((rc = run_pass(c, 1, frame, 1, nullptr)) != RT_OK) return rc;
+    if ((rc = finish_pass(c, c->npix)) != RT_OK) return rc;
+    end_call(c);
+    return download_vec3(c, c->rad.as<float4>(), c->npix, rgb);
+}
+
+static int bsdf_common(rt_ctx* c, uint32_t n, const rt_material* mats, const float* eta, const float* V, const float* N,
+                       const float* L, const float* r, float* out_L, float* out_f, float* out_pdf) {
+    int rc;
+    if ((rc = bind_device(c)) != RT_OK) return rc;
+    if (n == 0) return RT_OK;
+    DevBuf dm, de, dv, dn, dl, dr, oL, of, op;
+    auto put = [&](DevBuf& b, const void* src, size_t bytes) -> hipError_t {
+        hipError_t e = b.ensure(bytes);
+        if (e == hipSuccess && src) e = hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice);
+        return e;
+    };
+    HIPCHK(c, put(dm, mats, size_t(n) * sizeof(rt_material)));
+    HIPCHK(c, put(de, eta, size_t(n) * 4));
+    HIPCHK(c, put(dv, V, size_t(n) * 12));
+    HIPCHK(c, put(dn, N, size_t(n) * 12));
+    HIPCHK(c, put(dl, L, size_t(n) * 12));
+    HIPCHK(c, put(dr, r, size_t(n) * 8));
+    HIPCHK(c, put(oL, nullptr, size_t(n) * 12));
+    HIPCHK(c, put(of, nullptr, size_t(n) * 12));
+    HIPCHK(c, put(op, nullptr, size_t(n) * 4));
+    BsdfIo io{dm.as<float4>(), de.as<float>(), dv.as<float>(), dn.as<float>(), dl.as<float>(), dr.as<float>(), oL.as<float>(), of.as<float>(), op.as<float>()};
+    hipLaunchKernelGGL(k_bsdf, dim3((n + 63) / 64), dim3(64), 0, c->stream, io, n, r ? 1 : 0);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (out_L) HIPCHK(c, hipMemcpy(out_L, oL.p, size_t(n) * 12, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(out_f, of.p, size_t(n) * 12, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(out_pdf, op.p, size_t(n) * 4, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+extern "C" int rt_eval_bsdf(rt_ctx* c, uint32_t n, const rt_material* mats, const float* eta, const float* V, const float* N,
+                            const float* L, float* out_f, float* out_pdf) {
+    if (!c) return RT_ERR_INVALID;
+    if (n && (!mats || !eta || !V || !N || !L || !out_f || !out_pdf)) return fail(c, RT_ERR_INVALID, "rt_eval_bsdf: null argument");
+    return bsdf_common(c, n, mats, eta, V, N, L, nullptr, nullptr, out_f, out_pdf);
+}
+
+extern "C" int rt_sample_bsdf(rt_ctx* c, uint32_t n, const rt_material* mats, const float* eta, const float* V, const float* N,
+                              const float* r1r2, float* out_L, float* out_f, float* out_pdf) {
+    if (!c) return RT_ERR_INVALID;
+    if (n && (!mats || !eta || !V || !N || !r1r2 || !out_L || !out_f || !out_pdf)) return fail(c, RT_ERR_INVALID, "rt_sample_bsdf: null argument");
+    return bsdf_common(c, n, mats, eta, V, N, V, r1r2, out_L, out_f, out_pdf);
+}
+
+extern "C" int rt_sample_texture(rt_ctx* c, uint32_t tex, uint32_t n, const float* uvw, float* rgba) {
+    if (!c) return RT_ERR_INVALID;
+    if (n && (!uvw || !rgba)) return fail(c, RT_ERR_INVALID, "rt_sample_texture: null argument");
+    if (tex != 0xFFFFFFFFu && tex >= c->sd.tex.n_tex) return fail(c, RT_ERR_INVALID, "rt_sample_texture: texture index out of range");
+    int rc;
+    if ((rc = bind_device(c)) != RT_OK) return rc;
+    if (n == 0) return RT_OK;
+    DevBuf in, out;
+    HIPCHK(c, in.ensure(size_t(n) * 12));
+    HIPCHK(c, out.ensure(size_t(n) * 16));
+    HIPCHK(c, hipMemcpy(in.p, uvw, size_t(n) * 12, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_sample_texture, dim3((n + 63) / 64), dim3(64), 0, c->stream, c->sd.tex, tex, n, in.as<float>(), out.as<float4>());
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(rgba, out.p, size_t(n) * 16, hipMemcpyDeviceToHost));
+    return RT_OK;
+}

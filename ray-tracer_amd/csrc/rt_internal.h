@@ -1,0 +1,63 @@
+// Internal declarations shared by the translation units of librt_hip.so. Not part of the ABI.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "rt_api.h"
+
+namespace rtint {
+
+// Records `msg` for rt_last_error (in the context when there is one, else thread-local) and returns `code`.
+int fail(rt_ctx* ctx, int code, const std::string& msg);
+void set_ctx_error(rt_ctx* ctx, const std::string& msg);  // defined next to the context type
+const char* thread_error();                               // message of the last context-less failure on this thread
+
+// ---- device-side data layout, produced on the host from the wire-format scene ----
+
+// 64-byte record for one interior node: the boxes of BOTH children plus how to continue into each,
+// so one visit costs four 16-byte loads instead of two dependent 32-byte node fetches.
+//   q0 = {l.min.x, l.min.y, l.min.z, l.max.x}   q1 = {l.max.y, l.max.z, r.min.x, r.min.y}
+//   q2 = {r.min.z, r.max.x, r.max.y, r.max.z}   q3 = {left_ref, right_ref, 0, 0}
+// A child reference is either the index of another record (bit 31 clear) or a leaf
+// (bit 31 set, bits 30..25 = triangle count - 1, bits 24..0 = first triangle).
+struct alignas(16) NodePair {
+    float q0[4], q1[4], q2[4];
+    uint32_t ref[4];
+};
+static_assert(sizeof(NodePair) == 64, "NodePair");
+
+constexpr uint32_t kLeafBit = 0x80000000u;
+constexpr uint32_t kLeafMaxCount = 64;
+constexpr uint32_t kLeafMaxFirst = 1u << 25;
+constexpr uint32_t kRefNone = 0x7FFFFFFFu;  // "empty scene" root marker: nothing to traverse
+
+inline uint32_t make_leaf_ref(uint32_t first, uint32_t count) { return kLeafBit | ((count - 1u) << 25) | first; }
+
+// 48-byte intersection record: {v0, n.x} {v1-v0, n.y} {v2-v0, n.z}, n = unit plane normal.
+struct alignas(16) TriIsect {
+    float a[4], b[4], c[4];
+};
+// 64-byte shading record: n0 n1 n2 (9 floats), uv0 uv1 uv2 (6 floats), matword.
+// matword = material index | bit 31: spec_trans > 0.5 | bit 30: shade_smooth.
+struct alignas(16) TriShade {
+    float n[9];
+    float uv[6];
+    uint32_t matword;
+};
+static_assert(sizeof(TriIsect) == 48 && sizeof(TriShade) == 64, "triangle streams");
+
+struct GpuScene {
+    std::vector<NodePair> nodes;
+    uint32_t root_ref = kRefNone;
+    std::vector<TriIsect> isect;
+    std::vector<TriShade> shade;
+};
+
+// Converts reference-layout nodes/triangles into the device layout. Returns RT_OK or an rt_status
+// (with `err` filled) when the input violates the traversal contract or a device-layout limit.
+int convert_scene(const rt_bvh_node* nodes, uint32_t n_nodes, const rt_triangle* tris, uint32_t n_tri,
+                  const rt_material* mats, uint32_t n_mat, GpuScene& out, std::string& err);
+
+}  // namespace rtint

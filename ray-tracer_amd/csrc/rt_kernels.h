@@ -1,0 +1,627 @@
+// Wavefront path-tracing kernels for gfx950 (MI355X): raygen, extend, shade, connect, accumulate.
+//
+// One work item = one path segment. Paths live in fixed "slots" (slot = frame_in_pass * n_pixels + pixel);
+// a stage processes a queue of slot indices and appends survivors to the next queue with a wave-level
+// ballot/popcount prefix and ONE atomic per wavefront. Queue lengths stay on the device: every kernel is a
+// fixed-size grid of persistent wavefronts that reads its work count from HBM, so a whole multi-bounce
+// sample is queued without a host round trip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_api.h"
+#include "rt_device_math.h"
+
+namespace rtdev {
+
+constexpr uint32_t kBlock = 256;          // 4 wavefronts per workgroup
+constexpr uint32_t kStackLds = 24;        // traversal stack entries kept in LDS per lane (24 KiB per workgroup)
+constexpr uint32_t kStackMax = 65;        // MAX_BVH_DEPTH + 1, main.comp:6 / intersects.comp:130
+constexpr uint32_t kLeafBit = 0x80000000u;
+constexpr uint32_t kRefNone = 0x7FFFFFFFu;
+constexpr uint32_t kNoPrim = 0xFFFFFFFFu;
+constexpr uint32_t kMaxBounces = 64;
+
+struct SceneDev {
+    const float4* __restrict__ nodes;     // 4 x float4 per interior record
+    const float4* __restrict__ isect;     // 3 x float4 per triangle
+    const float4* __restrict__ shade;     // 4 x float4 per triangle
+    const float4* __restrict__ mats;      // 6 x float4 per material
+    const float4* __restrict__ lights;    // 3 x float4 per analytic light
+    const float4* __restrict__ light_tris; // per emissive triangle: {v0, area} {v1, Le.r} {v2, Le.g} {unit normal, Le.b}
+    const float* __restrict__ cdf;        // un-normalised running power
+    uint32_t root_ref, n_tri, n_light, n_emissive;
+    uint32_t cdf_len_seen;                // length the light selector searches (true length unless the padded-length quirk is on)
+    TexView tex;
+};
+
+struct PathDev {
+    float4* __restrict__ ray_o;   // {origin, -}
+    float4* __restrict__ ray_d;   // {direction, -}
+    float4* __restrict__ hit;     // {t, u, v, prim bits}
+    float4* __restrict__ thr;     // {throughput rgb, pdf of the BSDF sample that produced the current ray}
+    float4* __restrict__ rad;     // {radiance rgb, RNG state bits}
+};
+
+struct ShadowQueue {
+    float4* __restrict__ o;       // {origin, tmax}
+    float4* __restrict__ d;       // {direction, slot bits}
+    float4* __restrict__ c;       // {contribution if unoccluded, -}
+};
+
+struct TraceStats {               // all 64-bit, updated with one atomic per wavefront
+    unsigned long long extend_rays, shadow_rays, camera_rays;
+    unsigned long long extend_node_pops, extend_leaf_pops, extend_tri_tests;
+    unsigned long long shadow_node_pops, shadow_leaf_pops, shadow_tri_tests;
+};
+
+// ---- wavefront primitives (64 lanes) -------------------------------------------------------------------
+RT_DEV uint32_t lane_id() { return __lane_id(); }
+
+// Every lane of the wavefront must call this (predicate false for lanes without work).
+// Returns the destination index for lanes with pred == true.
+RT_DEV uint32_t wave_append(bool pred, uint32_t* counter) {
+    unsigned long long mask = __ballot(pred);
+    uint32_t n = uint32_t(__popcll(mask));
+    uint32_t lane = lane_id();
+    uint32_t base = 0;
+    if (n != 0 && lane == 0) base = atomicAdd(counter, n);
+    base = __shfl(base, 0);
+    uint32_t rank = uint32_t(__popcll(mask & ((1ull << lane) - 1ull)));
+    return base + rank;
+}
+RT_DEV uint32_t wave_sum(uint32_t v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    return v;  // valid in lane 0
+}
+
+// ---- traversal -----------------------------------------------------------------------------------------
+// Closest hit with t < best_t on entry. Visit order and tie rules are those of hit_meshes
+// (intersects.comp:124-175): the nearer child first, on equal entry distance the right child first, a child
+// is entered only while its entry distance is strictly below the current hit distance, triangles of a leaf in
+// storage order with a strict "closer" test, so the first triangle tested wins an exact tie.
+// `stack` points at this lane's column of the workgroup's LDS stack (stride kBlock words).
+template <bool COUNT>
+RT_DEV void closest_hit(const SceneDev& sc, f3 o, f3 d, float& best_t, float& best_u, float& best_v, uint32_t& best_prim,
+                        uint32_t* stack, uint32_t& n_node, uint32_t& n_leaf, uint32_t& n_tri) {
+    uint32_t cur = sc.root_ref;
+    if (cur == kRefNone) return;
+    const f3 inv = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+    uint32_t sp = 0;
+    uint32_t spill[kStackMax - kStackLds];
+    for (;;) {
+        if (cur & kLeafBit) {
+            if (COUNT) ++n_leaf;
+            uint32_t first = cur & 0x01FFFFFFu;
+            uint32_t count = ((cur >> 25) & 63u) + 1u;
+            for (uint32_t k = 0; k < count; ++k) {
+                if (COUNT) ++n_tri;
+                const float4* tp = sc.isect + size_t(first + k) * 3;
+                float4 A = tp[0], B = tp[1], C = tp[2];
+                f3 pn = {A.w, B.w, C.w};
+                if (fabsf(dot(pn, d)) < kRayEps) continue;       // intersects.comp:42
+                f3 ab = xyz(B), ac = xyz(C);
+                f3 oo = o - xyz(A);
+                f3 p = cross(d, ac);
+                f3 q = cross(oo, ab);
+                float inv_det = 1.0f / dot(p, ab);
+                float t = dot(q, ac) * inv_det;
+                if (t < kRayEps) continue;                        // :52
+                float u = dot(p, oo) * inv_det;
+                float v = dot(q, d) * inv_det;
+                float w = 1.0f - u - v;
+                if (u < 0.0f || v < 0.0f || w < 0.0f || u > 1.0f || v > 1.0f || w > 1.0f) continue;  // :61
+                if (t < best_t) { best_t = t; best_u = u; best_v = v; best_prim = first + k; }
+            }
+        } else {
+            if (COUNT) ++n_node;
+            const float4* np = sc.nodes + size_t(cur) * 4;
+            float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+            // slab test per child, intersects.comp:103-121
+            f3 l1 = (f3{q0.x, q0.y, q0.z} - o) * inv, l2 = (f3{q0.w, q1.x, q1.y} - o) * inv;
+            f3 r1 = (f3{q1.z, q1.w, q2.x} - o) * inv, r2 = (f3{q2.y, q2.z, q2.w} - o) * inv;
+            float l_lo = fmaxf(fmaxf(fminf(l1.x, l2.x), fminf(l1.y, l2.y)), fminf(l1.z, l2.z));
+            float l_hi = fminf(fminf(fmaxf(l1.x, l2.x), fmaxf(l1.y, l2.y)), fmaxf(l1.z, l2.z));
+            float r_lo = fmaxf(fmaxf(fminf(r1.x, r2.x), fminf(r1.y, r2.y)), fminf(r1.z, r2.z));
+            float r_hi = fminf(fminf(fmaxf(r1.x, r2.x), fmaxf(r1.y, r2.y)), fmaxf(r1.z, r2.z));
+            float dl = (l_lo <= l_hi && l_hi > 0.0f) ? l_lo : INFINITY;
+            float dr = (r_lo <= r_hi && r_hi > 0.0f) ? r_lo : INFINITY;
+            uint32_t ref_l = __float_as_uint(q3.x), ref_r = __float_as_uint(q3.y);
+            bool go_l = dl < best_t, go_r = dr < best_t;
+            bool left_first = dl < dr;
+            uint32_t near_ref = left_first ? ref_l : ref_r, far_ref = left_first ? ref_r : ref_l;
+            bool go_near = left_first ? go_l : go_r, go_far = left_first ? go_r : go_l;
+            if (go_near) {
+                if (go_far) {
+                    if (sp < kStackLds) stack[sp * kBlock] = far_ref;
+                    else spill[sp - kStackLds] = far_ref;
+                    ++sp;
+                }
+                cur = near_ref;
+                continue;
+            }
+            if (go_far) { cur = far_ref; continue; }
+        }
+        if (sp == 0) break;
+        --sp;
+        cur = sp < kStackLds ? stack[sp * kBlock] : spill[sp - kStackLds];
+    }
+}
+
+// ---- kernels -------------------------------------------------------------------------------------------
+
+// Seed rule + thin-lens camera ray for every slot (main.comp:251; generate_ray.comp:2-29).
+__global__ __launch_bounds__(kBlock) void k_raygen(rt_camera cam, PathDev pd, uint32_t n_pixels, uint32_t n_slots,
+                                                   uint32_t frame_first, uint32_t frame_stride, uint32_t* seeds_out) {
+    const uint32_t W = cam.resolution[0];
+    const float* m = cam.rotation;
+    for (uint32_t slot = blockIdx.x * kBlock + threadIdx.x; slot < n_slots; slot += gridDim.x * kBlock) {
+        uint32_t pixel = slot % n_pixels;
+        uint32_t frame = frame_first + (slot / n_pixels) * frame_stride;
+        uint32_t px = pixel % W, py = pixel / W;
+        uint32_t seed = px + W * py + frame * py * px;
+        float k = cam.focus_distance / cam.focal_length;
+        float fpx = cam.view_port_uv[0] * k, fpy = cam.view_port_uv[1] * k;
+        float dx = fpx / float(cam.resolution[0]);
+        float dy = (fpy / float(cam.resolution[1])) * -1.0f;
+        f3 origin = f3{-fpx / 2.0f, fpy / 2.0f, -cam.focus_distance} + f3{dx / 2.0f, dy / 2.0f, 0.0f};
+        // pixel_offset with quadrant 0 (random.comp:16-27): jitter in [-0.5, 0)^2
+        float jx = pcg_next(seed) * 0.5f;
+        float jy = pcg_next(seed) * 0.5f;
+        jx += 0.0f; jy += 0.0f;
+        jx -= 0.5f; jy -= 0.5f;
+        f3 pix = origin + f3{dx * (float(px) + jx), dy * (float(py) + jy), 0.0f};
+        // random_disc (random.comp:30-35,54-57): two Box-Muller normals, normalised, times a uniform radius
+        float a1 = sqrtf(-2.0f * logf(1.0f - pcg_next(seed)));
+        float b1 = 2.0f * kPi * pcg_next(seed);
+        float n1 = cosf(b1) * fminf(a1, 1000000000.0f);
+        float a2 = sqrtf(-2.0f * logf(1.0f - pcg_next(seed)));
+        float b2 = 2.0f * kPi * pcg_next(seed);
+        float n2 = cosf(b2) * fminf(a2, 1000000000.0f);
+        float rn = 1.0f / sqrtf(n1 * n1 + n2 * n2);
+        float radius = pcg_next(seed);
+        f3 ap = f3{n1 * rn * radius, n2 * rn * radius, 0.0f} * cam.aperture_radius;
+        f3 dl = normalize(pix - ap);
+        f3 dw = {m[0] * dl.x + m[4] * dl.y + m[8] * dl.z, m[1] * dl.x + m[5] * dl.y + m[9] * dl.z,
+                 m[2] * dl.x + m[6] * dl.y + m[10] * dl.z};
+        f3 ow = f3{m[0] * ap.x + m[4] * ap.y + m[8] * ap.z, m[1] * ap.x + m[5] * ap.y + m[9] * ap.z,
+                   m[2] * ap.x + m[6] * ap.y + m[10] * ap.z} + f3{cam.location[0], cam.location[1], cam.location[2]};
+        (void)pcg_next(seed);  // ray.time
+        pd.ray_o[slot] = make_float4(ow.x, ow.y, ow.z, 0.0f);
+        pd.ray_d[slot] = make_float4(dw.x, dw.y, dw.z, 0.0f);
+        pd.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+        pd.rad[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(seed));
+        if (seeds_out) seeds_out[slot] = seed;
+    }
+}
+
+// extend: closest hit for every queued slot. queue == nullptr means the identity queue (bounce 0).
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_extend(SceneDev sc, PathDev pd, const uint32_t* __restrict__ queue,
+                                                   const uint32_t* __restrict__ count_ptr, uint32_t count_imm,
+                                                   TraceStats* stats) {
+    __shared__ uint32_t s_stack[kStackLds * kBlock];
+    const uint32_t n = count_ptr ? *count_ptr : count_imm;
+    uint32_t n_node = 0, n_leaf = 0, n_tri = 0;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        uint32_t slot = queue ? queue[i] : i;
+        float4 o4 = pd.ray_o[slot], d4 = pd.ray_d[slot];
+        float t = INFINITY, u = 0.0f, v = 0.0f;
+        uint32_t prim = kNoPrim;
+        closest_hit<COUNT>(sc, xyz(o4), xyz(d4), t, u, v, prim, s_stack + threadIdx.x, n_node, n_leaf, n_tri);
+        pd.hit[slot] = make_float4(t, u, v, __uint_as_float(prim));
+    }
+    if (COUNT) {
+        n_node = wave_sum(n_node); n_leaf = wave_sum(n_leaf); n_tri = wave_sum(n_tri);
+        if (lane_id() == 0) {
+            atomicAdd(&stats->extend_node_pops, (unsigned long long)n_node);
+            atomicAdd(&stats->extend_leaf_pops, (unsigned long long)n_leaf);
+            atomicAdd(&stats->extend_tri_tests, (unsigned long long)n_tri);
+        }
+    }
+}
+
+// connect: visibility of every queued light sample; adds the pre-weighted contribution when unoccluded.
+// Occluded = a closest hit nearer than tmax whose material is not glass-like (disney.comp:697-701,
+// intersects.comp:152-154). Each slot owns at most one entry per bounce, so the add needs no atomic.
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_connect(SceneDev sc, PathDev pd, ShadowQueue sq,
+                                                    const uint32_t* __restrict__ count_ptr, TraceStats* stats) {
+    __shared__ uint32_t s_stack[kStackLds * kBlock];
+    const uint32_t n = *count_ptr;
+    uint32_t n_node = 0, n_leaf = 0, n_tri = 0;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        float4 o4 = sq.o[i], d4 = sq.d[i];
+        float t = o4.w, u = 0.0f, v = 0.0f;
+        uint32_t prim = kNoPrim;
+        closest_hit<COUNT>(sc, xyz(o4), xyz(d4), t, u, v, prim, s_stack + threadIdx.x, n_node, n_leaf, n_tri);
+        bool blocked = false;
+        if (prim != kNoPrim) blocked = (__float_as_uint(sc.shade[size_t(prim) * 4 + 3].w) & 0x80000000u) == 0u;
+        if (!blocked) {
+            uint32_t slot = __float_as_uint(d4.w);
+            float4 c = sq.c[i];
+            float4 r = pd.rad[slot];
+            r.x += c.x; r.y += c.y; r.z += c.z;
+            pd.rad[slot] = r;
+        }
+    }
+    if (COUNT) {
+        n_node = wave_sum(n_node); n_leaf = wave_sum(n_leaf); n_tri = wave_sum(n_tri);
+        if (lane_id() == 0) {
+            atomicAdd(&stats->shadow_node_pops, (unsigned long long)n_node);
+            atomicAdd(&stats->shadow_leaf_pops, (unsigned long long)n_leaf);
+            atomicAdd(&stats->shadow_tri_tests, (unsigned long long)n_tri);
+        }
+    }
+}
+
+struct ShadeParams {
+    uint32_t bounce, max_bounces, flags;
+    const uint32_t* in_queue;      // nullptr = identity
+    const uint32_t* in_count_ptr;  // nullptr = use in_count_imm
+    uint32_t in_count_imm;
+    uint32_t* out_queue;
+    uint32_t* out_count;
+    uint32_t* shadow_count;
+};
+
+// shade: everything ray_color does at one path vertex (main.comp:137-209) except the two traversals.
+__global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, PathDev pd, ShadowQueue sq, ShadeParams sp) {
+    const uint32_t n = sp.in_count_ptr ? *sp.in_count_ptr : sp.in_count_imm;
+    const uint32_t wave_base0 = (blockIdx.x * kBlock + threadIdx.x) & ~63u;
+    const uint32_t stride = gridDim.x * kBlock;
+    const int num_lights = int(sc.n_light + sc.n_emissive);
+    for (uint32_t base = wave_base0; base < n; base += stride) {   // wave-uniform trip count
+        const uint32_t i = base + lane_id();
+        const bool valid = i < n;
+        bool alive = false, want_shadow = false;
+        uint32_t slot = 0;
+        float4 sh_o = {}, sh_d = {}, sh_c = {};
+        if (valid) {
+            slot = sp.in_queue ? sp.in_queue[i] : i;
+            float4 h4 = pd.hit[slot], o4 = pd.ray_o[slot], d4 = pd.ray_d[slot], T4 = pd.thr[slot], R4 = pd.rad[slot];
+            f3 ro = xyz(o4), rd = xyz(d4), thr = xyz(T4), rad = xyz(R4);
+            float prev_pdf = T4.w;
+            uint32_t seed = __float_as_uint(R4.w);
+            uint32_t prim = __float_as_uint(h4.w);
+            if (prim == kNoPrim) {
+                f4 bg = sample_cube(sc.tex, rd);                          // main.comp:137-140
+                rad = rad + f3{bg.x, bg.y, bg.z} * thr;
+            } else {
+                const float t = h4.x, u = h4.y, v = h4.z, w = 1.0f - h4.y - h4.z;
+                const float4* ip = sc.isect + size_t(prim) * 3;
+                float4 A = ip[0], B = ip[1], C = ip[2];
+                const float4* ap = sc.shade + size_t(prim) * 4;
+                float4 s0 = ap[0], s1 = ap[1], s2 = ap[2], s3 = ap[3];
+                uint32_t matword = __float_as_uint(s3.w);
+                Mat m = load_material(sc.mats, matword & 0x3FFFFFFFu);
+                f3 untextured_emission = m.emission;
+                f3 ab = xyz(B), ac = xyz(C);
+                f3 pos = ro + rd * t;
+                float uvx = s2.y * w + s2.w * u + s3.y * v;
+                float uvy = s2.z * w + s3.x * u + s3.z * v;
+                f3 normal;
+                if (matword & 0x40000000u)
+                    normal = normalize(f3{s0.x, s0.y, s0.z} * w + f3{s0.w, s1.x, s1.y} * u + f3{s1.z, s1.w, s2.x} * v);
+                else
+                    normal = f3{A.w, B.w, C.w};
+                // texture modulation, main.comp:141-159
+                if (m.base_tex != 0xFFFFFFFFu) { f4 c = sample_2d(sc.tex, m.base_tex, uvx, uvy); m.base = m.base * f3{c.x, c.y, c.z}; }
+                if (m.mr_tex != 0xFFFFFFFFu) { f4 c = sample_2d(sc.tex, m.mr_tex, uvx, uvy); m.metallic *= c.z; m.roughness *= c.y; }
+                if (m.emission_tex != 0xFFFFFFFFu) { f4 c = sample_2d(sc.tex, m.emission_tex, uvx, uvy); m.emission = m.emission * f3{c.x, c.y, c.z}; }
+                if (m.normal_tex != 0xFFFFFFFFu) {
+                    f4 c = sample_2d(sc.tex, m.normal_tex, uvx, uvy);
+                    f3 tn = f3{c.x, c.y, c.z} * 2.0f - mk3(1.0f);
+                    float d1x = s2.w - s2.y, d1y = s3.x - s2.z, d2x = s3.y - s2.y, d2y = s3.z - s2.z;  // intersects.comp:82-89
+                    float f = 1.0f / (d1x * d2y - d2x * d1y);
+                    f3 tangent = normalize(f * (d2y * ab - d1y * ac));
+                    f3 bitangent = normalize(f * (-d2x * ab + d1x * ac));
+                    normal = normalize(tangent * tn.x + bitangent * tn.y + normal * tn.z);
+                }
+                f3 ffn = dot(normal, rd) <= 0.0f ? normal : -normal;      // main.comp:161
+                m.roughness = fmaxf(m.roughness, 0.001f);
+                float eta = dot(normal, ffn) > 0.0f ? (1.0f / m.ior) : m.ior;
+
+                // emitter hit, MIS against light sampling (main.comp:170-178; MeshLightPdf disney.comp:297-330)
+                float mis = 1.0f;
+                if (sp.bounce > 0 && sc.n_emissive != 0 && num_lights != 0) {
+                    float total_power = sc.cdf[sc.n_emissive - 1];
+                    float lum = luminance(untextured_emission);
+                    if (total_power > 0.0f && lum > 0.0f) {
+                        f3 ln = cross(ab, ac);
+                        float area = 0.5f * length(ln);
+                        if (area > 0.0f) {
+                            ln = ln / (2.0f * area);
+                            float cos_theta = fabsf(dot(ln, rd));
+                            if (cos_theta > 0.0f) {
+                                float select = (float(sc.n_emissive) / float(num_lights)) * ((area * lum) / total_power);
+                                float light_pdf = select * (t * t) / (area * cos_theta);
+                                if (light_pdf > 0.0f) mis = power_heuristic(prev_pdf, light_pdf);
+                            }
+                        }
+                    }
+                }
+                rad = rad + mis * m.emission * thr;
+
+                // "absorption" inside a transmissive medium, main.comp:182-184 (sign as upstream unless fixed)
+                if (dot(normal, ffn) < 0.0f && m.spec_trans > 0.0f) {
+                    float sgn = (sp.flags & RT_FIX_ABSORPTION) ? 1.0f : -1.0f;
+                    thr = thr * f3{expf(sgn * logf(m.base.x) * t), expf(sgn * logf(m.base.y) * t), expf(sgn * logf(m.base.z) * t)};
+                }
+
+                ShadePoint pt = make_shade_point(m, eta, -rd, ffn);
+
+                // next-event estimation: DirectLight, disney.comp:623-720
+                if (num_lights > 0) {
+                    f3 surface = pos + normal * kSurfEps;
+                    float light_rand = pcg_next(seed);
+                    int light_index = int(light_rand * float(num_lights));
+                    f3 ldir, lnormal, lemit;
+                    float ldist, lpdf;
+                    bool delta = false, have = true;
+                    if (light_index < int(sc.n_light)) {
+                        const float4* lp = sc.lights + size_t(light_index) * 3;
+                        float4 P = lp[0], E = lp[1], Ty = lp[2];
+                        delta = __float_as_uint(Ty.x) == 0u;
+                        ldir = xyz(P) - surface;
+                        ldist = length(ldir);
+                        float d2 = ldist * ldist;
+                        ldir = ldir / ldist;
+                        lnormal = -ldir;
+                        lemit = xyz(E);
+                        lpdf = 1.0f / d2;
+                        lpdf *= float(num_lights);
+                    } else {
+                        // SampleMeshCDF (disney.comp:270-288): binary search in the un-normalised CDF
+                        float cdf_rand = pcg_next(seed);
+                        int len = int(sc.cdf_len_seen);
+                        auto cdf_at = [&](int k) { return uint32_t(k) < sc.n_emissive ? sc.cdf[k] : 0.0f; };
+                        float total = cdf_at(len - 1);
+                        float target = cdf_rand * total;
+                        int lo = 0, hi = len - 1;
+                        while (lo < hi) {
+                            int mid = (lo + hi) >> 1;
+                            if (cdf_at(mid) < target) lo = mid + 1; else hi = mid;
+                        }
+                        float prev = lo > 0 ? cdf_at(lo - 1) : 0.0f;
+                        float tri_prob = (cdf_at(lo) - prev) / total;
+                        float select = (float(sc.n_emissive) / float(num_lights)) * tri_prob;
+                        // SampleMeshLight (disney.comp:230-264) on the device light table
+                        float r1 = pcg_next(seed);
+                        float r2 = pcg_next(seed);
+                        if (uint32_t(lo) < sc.n_emissive) {
+                            const float4* lt = sc.light_tris + size_t(lo) * 4;
+                            float4 L0 = lt[0], L1 = lt[1], L2 = lt[2], L3 = lt[3];
+                            float sq1 = sqrtf(r1);
+                            float bu = 1.0f - sq1, bv = r2 * sq1, bw = 1.0f - bu - bv;
+                            f3 lpnt = xyz(L0) * bu + xyz(L1) * bv + xyz(L2) * bw;
+                            ldir = lpnt - surface;
+                            ldist = length(ldir);
+                            float d2 = ldist * ldist;
+                            ldir = ldir / ldist;
+                            lnormal = xyz(L3);
+                            lemit = f3{L1.w, L2.w, L3.w};
+                            float cos_l = fabsf(dot(lnormal, -ldir));
+                            float area_pdf = d2 / (L0.w * fmaxf(cos_l, 0.0001f));
+                            lpdf = select * area_pdf;
+                        } else {
+                            have = false;
+                        }
+                    }
+                    if (have && dot(ldir, lnormal) < 0.0f) {
+                        float bpdf;
+                        f3 f = disney_eval(m, pt, ldir, bpdf);
+                        if (bpdf > 0.0f) {
+                            float weight = 1.0f;
+                            if (!delta && lpdf > 0.0f) weight = power_heuristic(lpdf, bpdf);
+                            f3 Li = weight * f * lemit / lpdf;
+                            f3 contrib = Li * thr;
+                            if (!(contrib.x == 0.0f && contrib.y == 0.0f && contrib.z == 0.0f)) {
+                                want_shadow = true;
+                                sh_o = make_float4(surface.x, surface.y, surface.z, ldist - kSurfEps);
+                                sh_d = make_float4(ldir.x, ldir.y, ldir.z, __uint_as_float(slot));
+                                sh_c = make_float4(contrib.x, contrib.y, contrib.z, 0.0f);
+                            }
+                        }
+                    }
+                }
+
+                // continuation: BSDF sample, throughput, Russian roulette, next ray (main.comp:188-209).
+                // After the last bounce the shader's remaining work has no observable effect, so it is skipped.
+                if (sp.bounce + 1 < sp.max_bounces) {
+                    float r1 = pcg_next(seed);
+                    float r2 = pcg_next(seed);
+                    f3 L;
+                    float pdf;
+                    f3 f = disney_sample(m, pt, r1, r2, L, pdf);
+                    if (pdf > 0.0f) {
+                        thr = thr * (f / pdf);
+                        bool go = true;
+                        if (sp.bounce > 2) {
+                            float p = fmaxf(0.05f, fminf(0.95f, fmaxf(thr.x, fmaxf(thr.y, thr.z))));
+                            if (pcg_next(seed) > p) go = false;
+                            else thr = thr / p;
+                        }
+                        if (go) {
+                            alive = true;
+                            f3 no = pos + L * kRayEps;
+                            pd.ray_o[slot] = make_float4(no.x, no.y, no.z, 0.0f);
+                            pd.ray_d[slot] = make_float4(L.x, L.y, L.z, 0.0f);
+                            pd.thr[slot] = make_float4(thr.x, thr.y, thr.z, pdf);
+                        }
+                    }
+                }
+            }
+            pd.rad[slot] = make_float4(rad.x, rad.y, rad.z, __uint_as_float(seed));
+        }
+        // queue compaction: one atomic per wavefront and queue
+        uint32_t dst = wave_append(alive, sp.out_count);
+        if (alive) sp.out_queue[dst] = slot;
+        uint32_t sdst = wave_append(want_shadow, sp.shadow_count);
+        if (want_shadow) { sq.o[sdst] = sh_o; sq.d[sdst] = sh_d; sq.c[sdst] = sh_c; }
+    }
+}
+
+
+// ---- accumulate / display ------------------------------------------------------------------------------
+RT_DEV f3 suppress_fireflies(f3 c, float max_value) {  // main.comp:114-120
+    float lum = luminance(c);
+    if (lum > max_value) c = c * (max_value / lum);
+    return c;
+}
+RT_DEV float hable(float x) {
+    const float A = 0.15f, B = 0.50f, C = 0.10f, D = 0.20f, E = 0.02f, F = 0.30f;
+    return ((x * (A * x + C * B) + D * E) / (x * (A * x + B) + D * F)) - E / F;
+}
+RT_DEV f3 filmic_tone_map(f3 c) {  // main.comp:215-240
+    c = c * 1.5f;
+    f3 r = {hable(c.x), hable(c.y), hable(c.z)};
+    r = r / hable(11.2f);
+    float l = dot(r, f3{0.2126f, 0.7152f, 0.0722f});
+    r = mix3(mk3(l), r, 1.7f);
+    const float g = 1.0f / 2.4f;
+    return {powf(fmaxf(r.x, 0.0f), g), powf(fmaxf(r.y, 0.0f), g), powf(fmaxf(r.z, 0.0f), g)};
+}
+RT_DEV uint32_t unorm8(float x) {  // UNORM store: NaN and negatives give 0
+    if (!(x > 0.0f)) return 0u;
+    if (x >= 1.0f) return 255u;
+    return uint32_t(floorf(x * 255.0f + 0.5f));
+}
+RT_DEV uint32_t pack_rgba8(float r, float g, float b, float a) {
+    return unorm8(r) | (unorm8(g) << 8) | (unorm8(b) << 16) | (unorm8(a) << 24);
+}
+
+// Folds the finished samples of one pass into the accumulator, in frame order (main.comp:260-267).
+// HDR mode: fp32 RGBA sum with the sample count in alpha; a non-finite sample component contributes 0.
+// Legacy mode: the shader's running mean stored in 8-bit UNORM every frame, plus the tone-mapped framebuffer.
+__global__ __launch_bounds__(kBlock) void k_accumulate(PathDev pd, float4* __restrict__ sum, uint32_t* __restrict__ accum8,
+                                                       uint32_t* __restrict__ framebuffer, uint32_t n_pixels,
+                                                       uint32_t frames_in_pass, uint32_t frame_first, uint32_t frame_stride,
+                                                       uint32_t legacy8) {
+    for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < n_pixels; p += gridDim.x * kBlock) {
+        if (legacy8) {
+            uint32_t w = accum8[p];
+            float old[4] = {float(w & 255u) / 255.0f, float((w >> 8) & 255u) / 255.0f, float((w >> 16) & 255u) / 255.0f,
+                            float(w >> 24) / 255.0f};
+            f3 fb = {0, 0, 0};
+            float fa = 0.0f;
+            for (uint32_t f = 0; f < frames_in_pass; ++f) {
+                float4 r = pd.rad[size_t(f) * n_pixels + p];
+                f3 c = suppress_fireflies(f3{r.x, r.y, r.z}, 5.0f);
+                float alpha = 1.0f / float(frame_first + f * frame_stride + 1u);
+                float nw[4] = {mixf(old[0], c.x, alpha), mixf(old[1], c.y, alpha), mixf(old[2], c.z, alpha), mixf(old[3], 1.0f, alpha)};
+                fb = {nw[0], nw[1], nw[2]};
+                fa = nw[3];
+                w = pack_rgba8(nw[0], nw[1], nw[2], nw[3]);
+                for (int k = 0; k < 4; ++k) old[k] = float((w >> (8 * k)) & 255u) / 255.0f;
+            }
+            accum8[p] = w;
+            f3 tm = filmic_tone_map(fb);
+            framebuffer[p] = pack_rgba8(tm.x, tm.y, tm.z, fa);
+        } else {
+            float4 s = sum[p];
+            for (uint32_t f = 0; f < frames_in_pass; ++f) {
+                float4 r = pd.rad[size_t(f) * n_pixels + p];
+                f3 c = suppress_fireflies(f3{r.x, r.y, r.z}, 5.0f);
+                s.x += isfinite(c.x) ? c.x : 0.0f;
+                s.y += isfinite(c.y) ? c.y : 0.0f;
+                s.z += isfinite(c.z) ? c.z : 0.0f;
+                s.w += 1.0f;
+            }
+            sum[p] = s;
+        }
+    }
+}
+
+// Tone-maps the HDR mean into an RGBA8 framebuffer (what SaveFrame would write).
+__global__ __launch_bounds__(kBlock) void k_tonemap(const float4* __restrict__ sum, uint32_t* __restrict__ framebuffer, uint32_t n_pixels) {
+    for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < n_pixels; p += gridDim.x * kBlock) {
+        float4 s = sum[p];
+        float inv = s.w > 0.0f ? 1.0f / s.w : 0.0f;
+        f3 tm = filmic_tone_map(f3{s.x * inv, s.y * inv, s.z * inv});
+        framebuffer[p] = pack_rgba8(tm.x, tm.y, tm.z, s.w > 0.0f ? 1.0f : 0.0f);
+    }
+}
+
+__global__ void k_add_sum(float4* __restrict__ sum, const float4* __restrict__ other, uint32_t n_pixels) {
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n_pixels; p += gridDim.x * blockDim.x) {
+        float4 a = sum[p], b = other[p];
+        sum[p] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+}
+
+// End of a pass: fold the per-bounce queue lengths into the 64-bit totals and clear them for the next pass.
+__global__ void k_finish_pass(uint32_t* __restrict__ q_count, uint32_t* __restrict__ sh_count, uint32_t n_counts,
+                              uint32_t camera_rays, TraceStats* stats) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        unsigned long long e = camera_rays, s = 0;
+        for (uint32_t b = 1; b < n_counts; ++b) e += q_count[b];
+        for (uint32_t b = 0; b < n_counts; ++b) s += sh_count[b];
+        stats->extend_rays += e;
+        stats->shadow_rays += s;
+        stats->camera_rays += camera_rays;
+        for (uint32_t b = 0; b < n_counts; ++b) { q_count[b] = 0; sh_count[b] = 0; }
+    }
+}
+
+// ---- stage-level kernels on caller-supplied inputs -----------------------------------------------------
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_trace_rays(SceneDev sc, const float4* __restrict__ ro, const float4* __restrict__ rd,
+                                                       uint32_t n, int shadow, float4* __restrict__ hits, TraceStats* stats) {
+    __shared__ uint32_t s_stack[kStackLds * kBlock];
+    uint32_t n_node = 0, n_leaf = 0, n_tri = 0;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        float4 o4 = ro[i], d4 = rd[i];
+        float t = shadow ? o4.w : INFINITY, u = 0.0f, v = 0.0f;
+        uint32_t prim = kNoPrim;
+        closest_hit<COUNT>(sc, xyz(o4), xyz(d4), t, u, v, prim, s_stack + threadIdx.x, n_node, n_leaf, n_tri);
+        if (shadow) {
+            bool blocked = prim != kNoPrim && (__float_as_uint(sc.shade[size_t(prim) * 4 + 3].w) & 0x80000000u) == 0u;
+            hits[i] = make_float4(blocked ? 0.0f : 1.0f, 0.0f, 0.0f, __uint_as_float(prim));
+        } else {
+            hits[i] = make_float4(t, u, v, __uint_as_float(prim));
+        }
+    }
+    if (COUNT) {
+        n_node = wave_sum(n_node); n_leaf = wave_sum(n_leaf); n_tri = wave_sum(n_tri);
+        if (lane_id() == 0) {
+            atomicAdd(shadow ? &stats->shadow_node_pops : &stats->extend_node_pops, (unsigned long long)n_node);
+            atomicAdd(shadow ? &stats->shadow_leaf_pops : &stats->extend_leaf_pops, (unsigned long long)n_leaf);
+            atomicAdd(shadow ? &stats->shadow_tri_tests : &stats->extend_tri_tests, (unsigned long long)n_tri);
+        }
+    }
+}
+
+struct BsdfIo {
+    const float4* mats;   // 6 x float4 per input
+    const float* eta; const float* V; const float* N; const float* L; const float* r;
+    float* out_L; float* out_f; float* out_pdf;
+};
+__global__ void k_bsdf(BsdfIo io, uint32_t n, int do_sample) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        Mat m = load_material(io.mats, i);
+        ShadePoint pt = make_shade_point(m, io.eta[i], f3{io.V[3 * i], io.V[3 * i + 1], io.V[3 * i + 2]},
+                                         f3{io.N[3 * i], io.N[3 * i + 1], io.N[3 * i + 2]});
+        float pdf;
+        f3 f;
+        if (do_sample) {
+            f3 L = {0, 0, 0};
+            f = disney_sample(m, pt, io.r[2 * i], io.r[2 * i + 1], L, pdf);
+            io.out_L[3 * i] = L.x; io.out_L[3 * i + 1] = L.y; io.out_L[3 * i + 2] = L.z;
+        } else {
+            f = disney_eval(m, pt, f3{io.L[3 * i], io.L[3 * i + 1], io.L[3 * i + 2]}, pdf);
+        }
+        io.out_f[3 * i] = f.x; io.out_f[3 * i + 1] = f.y; io.out_f[3 * i + 2] = f.z;
+        io.out_pdf[i] = pdf;
+    }
+}
+__global__ void k_sample_texture(TexView tv, uint32_t tex, uint32_t n, const float* __restrict__ uvw, float4* __restrict__ out) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        f4 c = tex == 0xFFFFFFFFu ? sample_cube(tv, f3{uvw[3 * i], uvw[3 * i + 1], uvw[3 * i + 2]})
+                                  : sample_2d(tv, tex, uvw[3 * i], uvw[3 * i + 1]);
+        out[i] = make_float4(c.x, c.y, c.z, c.w);
+    }
+}
+
+}  // namespace rtdev

@@ -1,0 +1,231 @@
+// Host-side scene packing: light table, scene blob, camera block and the wire-format -> device-layout converter.
+// Pure CPU code (no HIP calls); compiled into librt_hip.so.
+
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rt_api.h"
+#include "rt_internal.h"
+
+namespace rtint {
+
+static thread_local std::string g_thread_error;
+
+int fail(rt_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) set_ctx_error(ctx, msg);
+    else g_thread_error = msg;
+    return code;
+}
+
+const char* thread_error() { return g_thread_error.c_str(); }
+
+static inline uint64_t pad16(uint64_t n) { return (n + 15u) & ~uint64_t(15); }
+
+int convert_scene(const rt_bvh_node* nodes, uint32_t n_nodes, const rt_triangle* tris, uint32_t n_tri,
+                  const rt_material* mats, uint32_t n_mat, GpuScene& out, std::string& err) {
+    out = GpuScene{};
+    out.isect.resize(n_tri);
+    out.shade.resize(n_tri);
+    for (uint32_t i = 0; i < n_tri; ++i) {
+        const rt_triangle& t = tris[i];
+        if (t.material_idx >= n_mat) {
+            err = "triangle " + std::to_string(i) + " references material " + std::to_string(t.material_idx) +
+                  " but only " + std::to_string(n_mat) + " exist";
+            return RT_ERR_INVALID;
+        }
+        float ab[3], ac[3];
+        for (int k = 0; k < 3; ++k) { ab[k] = t.v[1][k] - t.v[0][k]; ac[k] = t.v[2][k] - t.v[0][k]; }
+        // plane normal = normalize(cross(ab, ac)), evaluated exactly as hit_triangle does per ray
+        // (intersects.comp:37-39): products and differences individually rounded, then v * (1/sqrt(v.v)).
+        float cx = ab[1] * ac[2] - ac[1] * ab[2];
+        float cy = ab[2] * ac[0] - ac[2] * ab[0];
+        float cz = ab[0] * ac[1] - ac[0] * ab[1];
+        float len2 = cx * cx + cy * cy + cz * cz;
+        float inv = 1.0f / std::sqrt(len2);
+        TriIsect& q = out.isect[i];
+        q.a[0] = t.v[0][0]; q.a[1] = t.v[0][1]; q.a[2] = t.v[0][2]; q.a[3] = cx * inv;
+        q.b[0] = ab[0];     q.b[1] = ab[1];     q.b[2] = ab[2];     q.b[3] = cy * inv;
+        q.c[0] = ac[0];     q.c[1] = ac[1];     q.c[2] = ac[2];     q.c[3] = cz * inv;
+        TriShade& s = out.shade[i];
+        for (int v = 0; v < 3; ++v)
+            for (int k = 0; k < 3; ++k) s.n[v * 3 + k] = t.n[v][k];
+        for (int v = 0; v < 3; ++v) { s.uv[v * 2] = t.uv[v][0]; s.uv[v * 2 + 1] = t.uv[v][1]; }
+        const rt_material& m = mats[t.material_idx];
+        if (t.material_idx >= (1u << 30)) { err = "material index too large"; return RT_ERR_UNSUPPORTED; }
+        s.matword = t.material_idx | (m.spec_trans > 0.5f ? 0x80000000u : 0u) | (m.shade_smooth ? 0x40000000u : 0u);
+    }
+
+    if (n_tri == 0 || n_nodes == 0) { out.root_ref = kRefNone; return RT_OK; }
+
+    auto leaf_ref = [&](const rt_bvh_node& nd, uint32_t& ref) -> bool {
+        if (nd.amt > kLeafMaxCount || nd.idx >= kLeafMaxFirst || uint64_t(nd.idx) + nd.amt > n_tri) return false;
+        ref = make_leaf_ref(nd.idx, nd.amt);
+        return true;
+    };
+
+    const rt_bvh_node& root = nodes[0];
+    if (root.amt != 0) {
+        if (!leaf_ref(root, out.root_ref)) { err = "root leaf range invalid or larger than 64 triangles"; return RT_ERR_UNSUPPORTED; }
+        return RT_OK;
+    }
+
+    // Interior nodes are renumbered in the order a depth-first walk meets them, which keeps a subtree's
+    // records contiguous in memory (the reference's builders already emit nodes depth-first).
+    std::vector<uint32_t> record_of(n_nodes, 0xFFFFFFFFu);
+    std::vector<uint32_t> stack{0};
+    std::vector<uint32_t> interior_order;
+    std::vector<uint8_t> seen(n_nodes, 0);
+    while (!stack.empty()) {
+        uint32_t i = stack.back();
+        stack.pop_back();
+        if (i >= n_nodes) { err = "node index out of range"; return RT_ERR_INVALID; }
+        if (seen[i]) { err = "BVH is not a tree (node reached twice)"; return RT_ERR_INVALID; }
+        seen[i] = 1;
+        const rt_bvh_node& nd = nodes[i];
+        if (nd.amt != 0) continue;
+        if (uint64_t(nd.idx) + 1 >= n_nodes) { err = "interior node child index out of range"; return RT_ERR_INVALID; }
+        record_of[i] = uint32_t(interior_order.size());
+        interior_order.push_back(i);
+        stack.push_back(nd.idx + 1);
+        stack.push_back(nd.idx);
+    }
+    out.nodes.resize(interior_order.size());
+    for (size_t r = 0; r < interior_order.size(); ++r) {
+        const rt_bvh_node& nd = nodes[interior_order[r]];
+        const rt_bvh_node& L = nodes[nd.idx];
+        const rt_bvh_node& R = nodes[nd.idx + 1];
+        NodePair& p = out.nodes[r];
+        p.q0[0] = L.min[0]; p.q0[1] = L.min[1]; p.q0[2] = L.min[2]; p.q0[3] = L.max[0];
+        p.q1[0] = L.max[1]; p.q1[1] = L.max[2]; p.q1[2] = R.min[0]; p.q1[3] = R.min[1];
+        p.q2[0] = R.min[2]; p.q2[1] = R.max[0]; p.q2[2] = R.max[1]; p.q2[3] = R.max[2];
+        const rt_bvh_node* kids[2] = {&L, &R};
+        for (int k = 0; k < 2; ++k) {
+            if (kids[k]->amt != 0) {
+                if (!leaf_ref(*kids[k], p.ref[k])) {
+                    err = "leaf range invalid, larger than 64 triangles, or beyond 2^25 triangles";
+                    return RT_ERR_UNSUPPORTED;
+                }
+            } else {
+                p.ref[k] = record_of[nd.idx + k];
+            }
+        }
+        p.ref[2] = p.ref[3] = 0;
+    }
+    out.root_ref = 0;
+    return RT_OK;
+}
+
+}  // namespace rtint
+
+using rtint::fail;
+
+extern "C" const char* rt_version(void) { return "rt_hip 0.1 (gfx950)"; }
+
+extern "C" int rt_build_lights(const rt_triangle* tris, uint32_t n_tri, const rt_material* mats, uint32_t n_mat,
+                               rt_emissive_tri* emissive, float* cdf, uint32_t* n_emissive, float* total_power) {
+    if ((n_tri && (!tris || !emissive || !cdf)) || !n_emissive) return fail(nullptr, RT_ERR_INVALID, "rt_build_lights: null argument");
+    uint32_t n = 0;
+    float total = 0.0f, running = 0.0f;
+    for (uint32_t i = 0; i < n_tri; ++i) {
+        const rt_triangle& t = tris[i];
+        if (t.material_idx >= n_mat) continue;  // upstream skips out-of-range material indices silently
+        const float* e = mats[t.material_idx].emission;
+        if (!(e[0] * e[0] + e[1] * e[1] + e[2] * e[2] > 0.0f)) continue;
+        float e1[3], e2[3];
+        for (int k = 0; k < 3; ++k) { e1[k] = t.v[1][k] - t.v[0][k]; e2[k] = t.v[2][k] - t.v[0][k]; }
+        float cx = e1[1] * e2[2] - e1[2] * e2[1];
+        float cy = e1[2] * e2[0] - e1[0] * e2[2];
+        float cz = e1[0] * e2[1] - e1[1] * e2[0];
+        float area = std::sqrt(cx * cx + cy * cy + cz * cz) * 0.5f;
+        float lum = e[0] * 0.2126f + e[1] * 0.7152f + e[2] * 0.0722f;
+        float power = lum * area;
+        if (!(power > 0.0f)) continue;
+        emissive[n] = rt_emissive_tri{i, t.material_idx, area, power};
+        total += power;
+        running += power;
+        cdf[n] = running;
+        ++n;
+    }
+    *n_emissive = n;
+    if (total_power) *total_power = total;
+    return RT_OK;
+}
+
+extern "C" int rt_scene_buffer_sizes(uint32_t n_bvh, uint32_t n_mat, uint32_t n_tri, uint32_t n_light,
+                                     uint32_t n_emissive, uint64_t sizes[6]) {
+    if (!sizes) return fail(nullptr, RT_ERR_INVALID, "rt_scene_buffer_sizes: null sizes");
+    sizes[0] = rtint::pad16(uint64_t(n_bvh) * sizeof(rt_bvh_node));
+    sizes[1] = rtint::pad16(uint64_t(n_mat) * sizeof(rt_material));
+    sizes[2] = rtint::pad16(uint64_t(n_tri) * sizeof(rt_triangle));
+    sizes[3] = rtint::pad16(uint64_t(n_light) * sizeof(rt_light));
+    sizes[4] = rtint::pad16(uint64_t(n_emissive) * sizeof(rt_emissive_tri));
+    sizes[5] = rtint::pad16(uint64_t(n_emissive) * sizeof(float));
+    return RT_OK;
+}
+
+extern "C" int rt_scene_write_buffers(const rt_bvh_node* nodes, uint32_t n_bvh, const rt_material* mats, uint32_t n_mat,
+                                      const rt_triangle* tris, uint32_t n_tri, const rt_light* lights, uint32_t n_light,
+                                      const rt_emissive_tri* emissive, const float* cdf, uint32_t n_emissive,
+                                      void* blob, uint64_t blob_capacity) {
+    uint64_t sz[6];
+    rt_scene_buffer_sizes(n_bvh, n_mat, n_tri, n_light, n_emissive, sz);
+    uint64_t total = sz[0] + sz[1] + sz[2] + sz[3] + sz[4] + sz[5];
+    if (!blob || blob_capacity < total) return fail(nullptr, RT_ERR_INVALID, "rt_scene_write_buffers: blob too small");
+    uint8_t* p = static_cast<uint8_t*>(blob);
+    std::memset(p, 0, total);
+    const void* src[6] = {nodes, mats, tris, lights, emissive, cdf};
+    const uint64_t bytes[6] = {uint64_t(n_bvh) * sizeof(rt_bvh_node),      uint64_t(n_mat) * sizeof(rt_material),
+                               uint64_t(n_tri) * sizeof(rt_triangle),      uint64_t(n_light) * sizeof(rt_light),
+                               uint64_t(n_emissive) * sizeof(rt_emissive_tri), uint64_t(n_emissive) * sizeof(float)};
+    for (int s = 0; s < 6; ++s) {
+        if (bytes[s]) {
+            if (!src[s]) return fail(nullptr, RT_ERR_INVALID, "rt_scene_write_buffers: null section with non-zero count");
+            std::memcpy(p, src[s], bytes[s]);
+        }
+        p += sz[s];
+    }
+    return RT_OK;
+}
+
+extern "C" int rt_camera_look_at(rt_camera* cam, uint32_t width, uint32_t height, const float location[3],
+                                 const float look_at[3], float focal_length, float focus_distance, float aperture_radius) {
+    if (!cam || !location || !look_at || width == 0 || height == 0) return fail(nullptr, RT_ERR_INVALID, "rt_camera_look_at: bad argument");
+    std::memset(cam, 0, sizeof(*cam));
+    cam->resolution[0] = width;
+    cam->resolution[1] = height;
+    float ratio = float(width) / float(height);
+    if (ratio > 1.0f) { cam->view_port_uv[0] = ratio; cam->view_port_uv[1] = 1.0f; }
+    else { cam->view_port_uv[0] = 1.0f; cam->view_port_uv[1] = 1.0f / ratio; }
+    cam->focal_length = focal_length;
+    cam->focus_distance = focus_distance;
+    cam->aperture_radius = aperture_radius;
+    for (int k = 0; k < 3; ++k) cam->location[k] = location[k];
+
+    auto norm = [](float v[3]) {
+        float r = 1.0f / std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        v[0] *= r; v[1] *= r; v[2] *= r;
+    };
+    auto cross = [](const float a[3], const float b[3], float o[3]) {
+        o[0] = a[1] * b[2] - b[1] * a[2];
+        o[1] = a[2] * b[0] - b[2] * a[0];
+        o[2] = a[0] * b[1] - b[0] * a[1];
+    };
+    auto dot = [](const float a[3], const float b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+    // right-handed look-at: f = forward, s = right, u = up; the stored matrix is its transpose, whose
+    // upper-left 3x3 has columns s, u, -f (camera -> world).
+    float f[3] = {look_at[0] - location[0], look_at[1] - location[1], look_at[2] - location[2]};
+    norm(f);
+    const float up[3] = {0.0f, 1.0f, 0.0f};
+    float s[3], u[3];
+    cross(f, up, s);
+    norm(s);
+    cross(s, f, u);
+    float* m = cam->rotation;  // column-major
+    m[0] = s[0];  m[1] = s[1];  m[2] = s[2];   m[3] = -dot(location, s);
+    m[4] = u[0];  m[5] = u[1];  m[6] = u[2];   m[7] = -dot(location, u);
+    m[8] = -f[0]; m[9] = -f[1]; m[10] = -f[2]; m[11] = dot(location, f);
+    m[12] = 0.0f; m[13] = 0.0f; m[14] = 0.0f;  m[15] = 1.0f;
+    return RT_OK;
+}
