@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s (extend + shadow) and 1080p samples/s of the wavefront path tracer on the
+Sponza-sized synthetic hall (`atrium-262k`, 1920x1080, 8 bounces) — BASELINE.json configs[1].
+
+One step = one sample per pixel over the full frame. `python bench.py --gpus N --steps K --warmup W`;
+for N > 1 launch with torch.distributed.run (one rank per GPU). Each rank renders the full frame for its
+own slice of the global frame indices (rank, rank+N, ...) with the scene replicated, and the fp32 accumulation
+buffers are sum-reduced with one RCCL all-reduce inside the timed region. Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--bounces", type=int, default=8)
+    ap.add_argument("--scene", default="atrium")
+    ap.add_argument("--scale", type=float, default=1.0, help="triangle-count scale of the synthetic scene (1.0 = the named config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--frames-per-pass", type=int, default=0)
+    return ap.parse_args()
+
+
+class _DevArray:
+    """Exposes a raw device pointer through __cuda_array_interface__ so torch can wrap it without a copy."""
+
+    def __init__(self, ptr, n_floats):
+        self.__cuda_array_interface__ = {"shape": (n_floats,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+
+def algorithmic_bytes_extend(rays, node_pops, tri_tests):
+    # per ray: 32 B ray in + 16 B hit out + 32 B root node; per interior node popped: two 32-B child boxes; per triangle test: 48 B
+    return rays * (32 + 16 + 32) + node_pops * 64 + tri_tests * 48
+
+
+def algorithmic_bytes_connect(rays, node_pops, tri_tests):
+    # per shadow ray: 32 B ray + 16 B queued contribution in, 4 B result, 32 B root node
+    return rays * (32 + 16 + 4 + 32) + node_pops * 64 + tri_tests * 48
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    n_gpus = args.gpus
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    elif n_gpus > 1:
+        print("bench.py: --gpus > 1 needs torch.distributed.run (one rank per GPU)", file=sys.stderr)
+        sys.exit(2)
+
+    import ray_tracer_amd as rt
+    from ray_tracer_amd import api, scenes
+
+    gen = scenes.GENERATORS[args.scene]
+    kw = {"width": args.width, "height": args.height}
+    if args.scene != "cornell":
+        kw["scale"] = args.scale
+    t0 = time.time()
+    scene = gen(**kw).finalize()
+    t_scene = time.time() - t0
+
+    r = rt.HipRenderer.create(scene, max_bounces=args.bounces, device=local_rank, frames_per_pass=args.frames_per_pass)
+    r.set_frame_slice(rank, world)
+    npix = args.width * args.height
+
+    red = None
+    if dist is not None:
+        import torch
+        ptr, nbytes = r.accum_device_buffer()
+        red = torch.as_tensor(_DevArray(ptr, nbytes // 4), device=torch.device("cuda", local_rank))
+
+    def barrier():
+        r.frame_complete()
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # ---- warm-up, then the timed region: exactly K steps (+ the accumulation reduce when N > 1)
+    r.render(args.warmup)
+    r.reset_accumulator()
+    r.reset_counters()
+    barrier()
+    t0 = time.perf_counter()
+    r.dispatch_compute(args.steps)
+    r.frame_complete()
+    if dist is not None:
+        import torch
+        dist.all_reduce(red, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    cnt = r.counters()
+    rays_local = cnt["extend_rays"] + cnt["shadow_rays"]
+
+    if dist is not None:
+        import torch
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        rr = torch.tensor([float(rays_local), float(cnt["extend_rays"]), float(cnt["shadow_rays"])], dtype=torch.float64, device="cuda")
+        dist.all_reduce(rr, op=dist.ReduceOp.SUM)
+        rays_total, ext_total, sh_total = (float(x) for x in rr.tolist())
+    else:
+        rays_total, ext_total, sh_total = float(rays_local), float(cnt["extend_rays"]), float(cnt["shadow_rays"])
+
+    result = {
+        "metric": "Mrays/s (extend+shadow), 1080p progressive path tracing",
+        "value": rays_total / elapsed / 1e6,
+        "unit": "Mrays/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed * 1e3 / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"{scene.name} {args.width}x{args.height}, {args.bounces} bounces, NEE+MIS, 1 spp per step per GPU",
+                   "triangles": int(len(scene.triangles)), "bvh_nodes": int(len(scene.bvh)), "emissive_tris": int(len(scene.emissive_tris)),
+                   "parallelism": f"sample-slice x{world}" if world > 1 else "single GPU", "frames_per_pass": int(args.frames_per_pass)},
+        "samples_per_sec": world * args.steps / elapsed,
+        "samples_per_sec_vs_rtx3080_readme_5_to_10": [world * args.steps / elapsed / 10.0, world * args.steps / elapsed / 5.0],
+        "value_div_8": rays_total / elapsed / 1e6 / 8.0,
+        "extend_rays": ext_total, "shadow_rays": sh_total,
+        "mpaths_per_sec": world * args.steps * npix / elapsed / 1e6,
+        "scene_build_s": t_scene, "bvh_build_ms": scene.bvh_stats.get("build_ms"),
+    }
+
+    # ---- roofline of the dominant kernel (extend), rank 0 only: HIP-event time per launch, algorithmic bytes from traversal counters
+    if rank == 0 and not args.no_roofline:
+        k = min(args.steps, 8)
+        rc = rt.HipRenderer.create(scene, max_bounces=args.bounces, device=local_rank, flags=api.RT_COUNT_TRAVERSAL,
+                                   frames_per_pass=args.frames_per_pass)
+        rc.render(k)
+        c = rc.counters()
+        rc.destroy()
+        rtm = rt.HipRenderer.create(scene, max_bounces=args.bounces, device=local_rank, flags=api.RT_KERNEL_TIMING,
+                                    frames_per_pass=args.frames_per_pass)
+        rtm.render(2)
+        rtm.reset_accumulator()
+        rtm.render(k)
+        tm = rtm.last_timer_perf()
+        rtm.destroy()
+        b_ext = algorithmic_bytes_extend(c["extend_rays"], c["extend_node_pops"], c["extend_tri_tests"])
+        b_con = algorithmic_bytes_connect(c["shadow_rays"], c["shadow_node_pops"], c["shadow_tri_tests"])
+        ext_s = tm["extend_ms"] / 1e3
+        achieved = b_ext / ext_s / 1e9 if ext_s > 0 else 0.0
+        result["roofline"] = {
+            "kernel": "k_extend", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "bytes_per_launch": b_ext / max(1, tm["extend_launches"]), "avg_launch_ms": tm["extend_ms"] / max(1, tm["extend_launches"]),
+            "launches": tm["extend_launches"], "samples": k,
+            "bytes_per_ray": b_ext / max(1, c["extend_rays"]),
+            "node_pops_per_ray": c["extend_node_pops"] / max(1, c["extend_rays"]),
+            "tri_tests_per_ray": c["extend_tri_tests"] / max(1, c["extend_rays"]),
+            "extend_mrays_per_s": c["extend_rays"] / ext_s / 1e6 if ext_s > 0 else 0.0,
+        }
+        con_s = tm["connect_ms"] / 1e3
+        result["kernel_ms_per_sample"] = {s: tm[f"{s}_ms"] / k for s in ("raygen", "extend", "shade", "connect", "accumulate")}
+        result["kernel_ms_per_sample"]["total"] = tm["total_ms"] / k
+        result["connect"] = {"achieved_GBs": b_con / con_s / 1e9 if con_s > 0 else 0.0,
+                             "mrays_per_s": c["shadow_rays"] / con_s / 1e6 if con_s > 0 else 0.0,
+                             "node_pops_per_ray": c["shadow_node_pops"] / max(1, c["shadow_rays"]),
+                             "tri_tests_per_ray": c["shadow_tri_tests"] / max(1, c["shadow_rays"])}
+
+    # ---- CPU baseline: the oracle (a restatement of the reference shader) on a bounded sample of the same workload
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import pyoracle as po
+        threads = args.cpu_threads or min(16, os.cpu_count() or 1)
+        o = po.OracleScene(scene)
+        sw, sh = max(16, args.width // 4), max(9, args.height // 4)
+        o.set_resolution(sw, sh)
+        t0 = time.perf_counter()
+        frames = 0
+        crays = 0
+        while True:
+            _, _, cc = o.render(1, args.bounces, first=frames, threads=threads)
+            crays += cc["rays"] + cc["shadow_rays"]
+            frames += 1
+            el = time.perf_counter() - t0
+            if el > 12.0 or frames >= 64:
+                break
+        result["cpu_baseline"] = {"value": crays / el / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+                                  "sample": f"{scene.name} at {sw}x{sh} (1/16 of the pixels), {frames} spp, {args.bounces} bounces, {el:.1f} s",
+                                  "samples_per_sec_at_full_res": frames / el / 16.0}
+
+    r.destroy()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

@@ -265,11 +265,12 @@ def atrium(width=1920, height=1080, scale=1.0, lights=True) -> Scene:
             zc = (Z - 1.25) * (1 if k % 2 else -1)
             mesh.quad([[xc - 0.4, 4.95, zc - 0.4], [xc + 0.4, 4.95, zc - 0.4], [xc + 0.4, 4.95, zc + 0.4], [xc - 0.4, 4.95, zc + 0.4]], LAMP)
     left = target - mesh.count()
-    if left < 0:
+    if left < 0 and scale >= 1.0:
         raise RuntimeError(f"atrium generator overshot its triangle budget by {-left}")
+    left = max(left, 0)   # reduced-scale variants keep their structural minimum
     mesh.pebbles(rng, left, [-X + 1, 0.02, -Z + 1], [X - 1, 0.12, Z - 1], 0.05, stone)
     cam = look_at_camera(width, height, (3.0, 2.0, 0.0), (-4.0, 2.0, 0.0), focal_length=1.0, focus_distance=55.0)
-    return Scene(triangles=mesh.triangles(), materials=mats, camera=cam, name="atrium-262k" if scale >= 1.0 else f"atrium-{target}")
+    return Scene(triangles=mesh.triangles(), materials=mats, camera=cam, name="atrium-262k" if scale >= 1.0 else f"atrium-{mesh.count()}")
 
 
 # ------------------------------------------------------------------------------------------- 3. glass blob
@@ -291,7 +292,7 @@ def glass_blob(width=1920, height=1080, scale=1.0, roughness=0.0) -> Scene:
 
     def blob(U, V):
         th, phi = np.pi * V, 2 * np.pi * U
-        rr = 1.0 + 0.18 * np.sin(5 * phi + ph[0]) * np.sin(4 * th + ph[1]) + 0.07 * np.sin(11 * phi + ph[2]) * np.sin(9 * th + ph[3])
+        rr = 1.0 + np.sin(th) * (0.18 * np.sin(5 * phi + ph[0]) * np.sin(4 * th + ph[1]) + 0.07 * np.sin(11 * phi + ph[2]) * np.sin(9 * th + ph[3]))
         return np.stack([rr * np.sin(th) * np.cos(phi), 1.3 + rr * np.cos(th), rr * np.sin(th) * np.sin(phi)], -1)
 
     nu, nv = max(8, int(260 * s)), max(6, int(260 * s))
@@ -299,11 +300,12 @@ def glass_blob(width=1920, height=1080, scale=1.0, roughness=0.0) -> Scene:
     mesh.quad([[-6, 0, 6], [6, 0, 6], [6, 0, -6], [-6, 0, -6]], 1)
     mesh.quad([[-1.5, 5.0, -1.5], [1.5, 5.0, -1.5], [1.5, 5.0, 1.5], [-1.5, 5.0, 1.5]], 2, split4=True)
     left = target - mesh.count()
-    if left < 0:
+    if left < 0 and scale >= 1.0:
         raise RuntimeError("glass_blob overshot its triangle budget")
+    left = max(left, 0)   # reduced-scale variants keep their structural minimum
     mesh.pebbles(rng, left, [-4, 0.01, -4], [4, 0.06, 4], 0.04, [1])
     cam = look_at_camera(width, height, (0.0, 2.2, 5.5), (0.0, 1.2, 0.0), focal_length=1.2, focus_distance=1.0)
-    return Scene(triangles=mesh.triangles(), materials=mats, camera=cam, name="glass-blob-135k" if scale >= 1.0 else f"glass-blob-{target}")
+    return Scene(triangles=mesh.triangles(), materials=mats, camera=cam, name="glass-blob-135k" if scale >= 1.0 else f"glass-blob-{mesh.count()}")
 
 
 # ------------------------------------------------------------------------------------------- 4/5. object soups
@@ -358,12 +360,13 @@ def car(width=1920, height=1080, scale=1.0, tex_size=2048, sky_size=512) -> Scen
     mesh._soup_base = mesh.count()
     _soup(rng, mesh, 260, int((target - mesh.count()) * 0.98), [-5, 0.3, -4], [5, 2.5, 4], np.arange(1, n_mat), 0.5)
     left = target - mesh.count()
-    if left < 0:
+    if left < 0 and scale >= 1.0:
         raise RuntimeError("car overshot its triangle budget")
+    left = max(left, 0)   # reduced-scale variants keep their structural minimum
     mesh.pebbles(rng, left, [-8, 0.01, -8], [8, 0.05, 8], 0.04, [48, 49, 50])
     cam = look_at_camera(width, height, (6.5, 2.4, 6.0), (0.0, 0.8, 0.0), focal_length=1.4, focus_distance=1.0)
     return Scene(triangles=mesh.triangles(), materials=mats, camera=cam, textures=[_noise_texture(rng, tex_size, (0.6, 0.55, 0.5))],
-                 skybox=_sky_cube(rng, sky_size), name="car-413k" if scale >= 1.0 else f"car-{target}")
+                 skybox=_sky_cube(rng, sky_size), name="car-413k" if scale >= 1.0 else f"car-{mesh.count()}")
 
 
 def interior(width=3840, height=2160, scale=1.0, tex_size=1024) -> Scene:
@@ -419,12 +422,13 @@ def interior(width=3840, height=2160, scale=1.0, tex_size=1024) -> Scene:
     mesh._soup_base = mesh.count()
     _soup(rng, mesh, 900, int((target - mesh.count()) * 0.985), [-X + 1, 0.3, -Z + 1], [X - 1, Y - 1.0, Z - 1], np.arange(6, 42), 0.45)
     left = target - mesh.count()
-    if left < 0:
+    if left < 0 and scale >= 1.0:
         raise RuntimeError("interior overshot its triangle budget")
+    left = max(left, 0)   # reduced-scale variants keep their structural minimum
     mesh.pebbles(rng, left, [-X + 0.5, 0.01, -Z + 0.5], [X - 0.5, 0.05, Z - 0.5], 0.03, np.arange(6, 20))
     cam = look_at_camera(width, height, (8.5, 1.7, 5.5), (-2.0, 1.2, -1.0), focal_length=1.0, focus_distance=1.0)
     return Scene(triangles=mesh.triangles(), materials=mats, camera=cam, textures=textures,
-                 name="interior-1.57M" if scale >= 1.0 else f"interior-{target}")
+                 name="interior-1.57M" if scale >= 1.0 else f"interior-{mesh.count()}")
 
 
 GENERATORS = {"cornell": cornell, "atrium": atrium, "glass_blob": glass_blob, "car": car, "interior": interior}

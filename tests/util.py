@@ -1,0 +1,73 @@
+"""Helpers shared by the tests."""
+import numpy as np
+
+from ray_tracer_amd import api
+from ray_tracer_amd.scene import Scene, default_material, look_at_camera, make_triangles
+
+
+def pcg_reference(seed, n):
+    """Independent pure-Python statement of random.comp:6-12 (words, states, floats)."""
+    words, states, floats = [], [], []
+    s = seed & 0xFFFFFFFF
+    for _ in range(n):
+        s = (s * 747796405 + 2891336453) & 0xFFFFFFFF
+        w = ((((s >> ((s >> 28) + 4)) ^ s) & 0xFFFFFFFF) * 277803737) & 0xFFFFFFFF
+        words.append(w)
+        states.append(s)
+        floats.append(np.float32(np.float32(w) / np.float32(4294967296.0)))
+    return words, states, floats
+
+
+def random_rays(rng, n, lo, hi):
+    o = rng.uniform(lo, hi, size=(n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    return o, d
+
+
+def chain_scene(depth=60):
+    """A deliberately deep, thin BVH: triangle k sits at z = k+1; every interior node has the remaining NEARER
+    triangles in its left (interior) child and the farthest one as its right leaf. A ray along +z therefore stacks
+    one far leaf per level: stack depth = `depth`, far beyond what the kernels keep in LDS."""
+    n = depth + 1
+    verts = np.zeros((n, 3, 3), np.float32)
+    for k in range(n):
+        z = float(k + 1)
+        verts[k] = [[-1, -1, z], [1, -1, z], [0, 1.5, z]]
+    tris = make_triangles(verts, None, None, np.zeros(n, np.uint32))
+    nodes = np.zeros(2 * n - 1, dtype=api.BVH_NODE)
+
+    def box(lo_k, hi_k):  # triangles lo_k..hi_k inclusive
+        return (-1, -1, lo_k + 1), (1, 1.5, hi_k + 1)
+
+    # node 0 covers all; interior i covers tris [0, n-1-level]
+    idx = 0
+    nxt = 1
+    level = 0
+    while True:
+        hi_k = n - 1 - level
+        mn, mx = box(0, hi_k)
+        nodes[idx]["min"], nodes[idx]["max"] = mn, mx
+        if hi_k == 0:
+            nodes[idx]["idx"], nodes[idx]["amt"] = 0, 1
+            break
+        nodes[idx]["idx"], nodes[idx]["amt"] = nxt, 0
+        left, right = nxt, nxt + 1
+        nxt += 2
+        mn, mx = box(hi_k, hi_k)
+        nodes[right]["min"], nodes[right]["max"] = mn, mx
+        nodes[right]["idx"], nodes[right]["amt"] = hi_k, 1
+        idx = left
+        level += 1
+    mats = default_material(1)
+    cam = look_at_camera(16, 16, (0.0, 0.0, -3.0), (0.0, 0.0, 0.0))
+    sc = Scene(triangles=tris, materials=mats, camera=cam, name=f"chain-{depth}")
+    sc.bvh = nodes[:nxt].copy()
+    sc.build_lights()
+    return sc
+
+
+def rel_close(a, b, rtol, atol):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    both_nan = np.isnan(a) & np.isnan(b)
+    return both_nan | (np.abs(a - b) <= atol + rtol * np.abs(b))
