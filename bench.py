@@ -41,13 +41,6 @@ def parse():
     return ap.parse_args()
 
 
-class _DevArray:
-    """Exposes a raw device pointer through __cuda_array_interface__ so torch can wrap it without a copy."""
-
-    def __init__(self, ptr, n_floats):
-        self.__cuda_array_interface__ = {"shape": (n_floats,), "typestr": "<f4", "data": (ptr, False), "version": 2}
-
-
 def algorithmic_bytes_extend(rays, node_pops, tri_tests):
     # per ray: 32 B ray in + 16 B hit out + 32 B root node; per interior node popped: two 32-B child boxes; per triangle test: 48 B
     return rays * (32 + 16 + 32) + node_pops * 64 + tri_tests * 48
@@ -65,7 +58,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     n_gpus = args.gpus
     dist = None
-    if world > 1:
+    # Library banners (RCCL prints one on stdout) must not mix with the single JSON line: park fd 1 on stderr until the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    if "RANK" in os.environ and "MASTER_ADDR" in os.environ:   # launched by torch.distributed.run (any world size)
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -86,14 +83,15 @@ def main():
     t_scene = time.time() - t0
 
     r = rt.HipRenderer.create(scene, max_bounces=args.bounces, device=local_rank, frames_per_pass=args.frames_per_pass)
-    r.set_frame_slice(rank, world)
+    from ray_tracer_amd.distributed import frame_slice
+    r.set_frame_slice(*frame_slice(rank, world))
     npix = args.width * args.height
 
     red = None
     if dist is not None:
         import torch
-        ptr, nbytes = r.accum_device_buffer()
-        red = torch.as_tensor(_DevArray(ptr, nbytes // 4), device=torch.device("cuda", local_rank))
+        from ray_tracer_amd.distributed import accumulator_tensor, reduce_accumulators
+        red = accumulator_tensor(r, torch.device("cuda", local_rank))   # zero-copy view of the library's fp32 sum buffer
 
     def barrier():
         r.frame_complete()
@@ -112,7 +110,7 @@ def main():
     r.frame_complete()
     if dist is not None:
         import torch
-        dist.all_reduce(red, op=dist.ReduceOp.SUM)
+        reduce_accumulators(red)          # one RCCL all-reduce of W*H*4 floats
         torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -216,8 +214,10 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":

@@ -12,7 +12,8 @@ from pathlib import Path
 import numpy as np
 
 PKG_DIR = Path(__file__).resolve().parent
-LIB_PATH = PKG_DIR / "librt_hip.so"
+# RT_HIP_LIB selects another build of the same library (kernel-variant experiments); there is still no non-HIP path.
+LIB_PATH = Path(os.environ.get("RT_HIP_LIB", PKG_DIR / "librt_hip.so"))
 
 # ---- wire records (include/rt_types.h) as numpy dtypes ---------------------------------------------------
 BVH_NODE = np.dtype([("min", "<f4", 3), ("idx", "<u4"), ("max", "<f4", 3), ("amt", "<u4")])

@@ -37,6 +37,13 @@ struct DevBuf {
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
+#ifndef RT_DYNAMIC
+#define RT_DYNAMIC 0
+#endif
+// Work distribution of the traversal kernels: a device-wide cursor (dynamic) or block-strided batches of 64 neighbouring items.
+#define RT_CURSOR(p) (RT_DYNAMIC ? (p) : nullptr)
+constexpr uint32_t kTraceBlocksPerCu = 8;   // persistent traversal grid: workgroups per CU (4 waves each)
+
 enum Stage { ST_RAYGEN = 0, ST_EXTEND, ST_SHADE, ST_CONNECT, ST_ACCUM, ST_COUNT };
 
 struct Span { int stage; hipEvent_t a, b; };
@@ -76,6 +83,9 @@ struct rt_ctx {
     ShadowQueue sq() const { return ShadowQueue{sq_o.as<float4>(), sq_d.as<float4>(), sq_c.as<float4>()}; }
     uint32_t* q_count() const { return counts.as<uint32_t>(); }
     uint32_t* sh_count() const { return counts.as<uint32_t>() + (kMaxBounces + 1); }
+    uint32_t* ext_cursor() const { return counts.as<uint32_t>() + 2 * (kMaxBounces + 1); }   // one work cursor per bounce
+    uint32_t* con_cursor() const { return counts.as<uint32_t>() + 3 * (kMaxBounces + 1); }
+    uint32_t* aux_cursor() const { return counts.as<uint32_t>() + 4 * (kMaxBounces + 1); }   // stage-level entry points
     TraceStats* tstats() const { return stats.as<TraceStats>(); }
 };
 
@@ -164,7 +174,7 @@ int alloc_paths(rt_ctx* c) {
     uint32_t fpp = c->fpp_cfg;
     if (c->flags & RT_REF_RGBA8_ACCUM) fpp = 1;
     if (fpp == 0) {
-        const uint64_t target = 4ull << 20;  // ~4 M paths in flight keep every CU fed through the late, sparse bounces
+        const uint64_t target = 16ull << 20;  // ~16 M paths in flight keep every CU fed through the late, sparse bounces (~2 GiB of path state)
         fpp = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(64, target / std::max<uint32_t>(1, c->npix))));
     }
     c->fpp = fpp;
@@ -212,15 +222,15 @@ int run_pass(rt_ctx* c, uint32_t frames, uint32_t frame_first, uint32_t frame_st
                            frame_first, frame_stride, seeds_out);
     }
     uint32_t* queues[2] = {c->q0.as<uint32_t>(), c->q1.as<uint32_t>()};
-    const uint32_t trace_grid = grid_for(c, n_slots, 6);
+    const uint32_t trace_grid = grid_for(c, n_slots, kTraceBlocksPerCu);
     const uint32_t shade_grid = grid_for(c, n_slots, 4);
     for (uint32_t b = 0; b < c->max_bounces; ++b) {
         const uint32_t* in_q = b == 0 ? nullptr : queues[b & 1];
         const uint32_t* in_n = b == 0 ? nullptr : c->q_count() + b;
         {
             StageTimer tm(c, ST_EXTEND);
-            if (count) hipLaunchKernelGGL(k_extend<true>, dim3(trace_grid), dim3(kBlock), 0, c->stream, c->sd, pd, in_q, in_n, n_slots, c->tstats());
-            else hipLaunchKernelGGL(k_extend<false>, dim3(trace_grid), dim3(kBlock), 0, c->stream, c->sd, pd, in_q, in_n, n_slots, c->tstats());
+            if (count) hipLaunchKernelGGL(k_extend<true>, dim3(trace_grid), dim3(kBlock), 0, c->stream, c->sd, pd, in_q, in_n, n_slots, RT_CURSOR(c->ext_cursor() + b), c->tstats());
+            else hipLaunchKernelGGL(k_extend<false>, dim3(trace_grid), dim3(kBlock), 0, c->stream, c->sd, pd, in_q, in_n, n_slots, RT_CURSOR(c->ext_cursor() + b), c->tstats());
         }
         {
             StageTimer tm(c, ST_SHADE);
@@ -229,8 +239,8 @@ int run_pass(rt_ctx* c, uint32_t frames, uint32_t frame_first, uint32_t frame_st
         }
         if (c->sd.n_light + c->sd.n_emissive != 0) {
             StageTimer tm(c, ST_CONNECT);
-            if (count) hipLaunchKernelGGL(k_connect<true>, dim3(trace_grid), dim3(kBlock), 0, c->stream, c->sd, pd, sq, c->sh_count() + b, c->tstats());
-            else hipLaunchKernelGGL(k_connect<false>, dim3(trace_grid), dim3(kBlock), 0, c->stream, c->sd, pd, sq, c->sh_count() + b, c->tstats());
+            if (count) hipLaunchKernelGGL(k_connect<true>, dim3(trace_grid), dim3(kBlock), 0, c->stream, c->sd, pd, sq, c->sh_count() + b, RT_CURSOR(c->con_cursor() + b), c->tstats());
+            else hipLaunchKernelGGL(k_connect<false>, dim3(trace_grid), dim3(kBlock), 0, c->stream, c->sd, pd, sq, c->sh_count() + b, RT_CURSOR(c->con_cursor() + b), c->tstats());
         }
     }
     HIPCHK(c, hipGetLastError());
@@ -238,7 +248,7 @@ int run_pass(rt_ctx* c, uint32_t frames, uint32_t frame_first, uint32_t frame_st
 }
 
 int finish_pass(rt_ctx* c, uint32_t n_slots) {
-    hipLaunchKernelGGL(k_finish_pass, dim3(1), dim3(64), 0, c->stream, c->q_count(), c->sh_count(), kMaxBounces + 1, n_slots, c->tstats());
+    hipLaunchKernelGGL(k_finish_pass, dim3(1), dim3(64), 0, c->stream, c->q_count(), c->sh_count(), c->ext_cursor(), kMaxBounces + 1, n_slots, c->tstats());
     HIPCHK(c, hipGetLastError());
     return RT_OK;
 }
@@ -290,7 +300,7 @@ extern "C" int rt_create(const rt_config* cfg, rt_ctx** out) {
     if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) c->n_cu = std::max(1, prop.multiProcessorCount);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return bail(RT_ERR_DEVICE); }
     if ((rc = alloc_paths(c)) != RT_OK) return bail(rc);
-    if (c->counts.ensure(sizeof(uint32_t) * 2 * (kMaxBounces + 1)) != hipSuccess || c->stats.ensure(sizeof(TraceStats)) != hipSuccess) {
+    if (c->counts.ensure(sizeof(uint32_t) * (4 * (kMaxBounces + 1) + 4)) != hipSuccess || c->stats.ensure(sizeof(TraceStats)) != hipSuccess) {
         c->err = "counter allocation failed"; return bail(RT_ERR_OOM);
     }
     (void)hipMemsetAsync(c->counts.p, 0, c->counts.bytes, c->stream);
@@ -619,10 +629,11 @@ static int trace_common(rt_ctx* c, uint32_t n, const float* origins, const float
     HIPCHK(c, hits.ensure(size_t(n) * 16));
     const bool count = (c->flags & RT_COUNT_TRAVERSAL) != 0;
     begin_call(c);
+    HIPCHK(c, hipMemsetAsync(c->aux_cursor(), 0, 4, c->stream));
     {
         StageTimer tm(c, shadow ? ST_CONNECT : ST_EXTEND);
-        if (count) hipLaunchKernelGGL(k_trace_rays<true>, dim3(grid_for(c, n, 6)), dim3(kBlock), 0, c->stream, c->sd, ro.as<float4>(), rd.as<float4>(), n, shadow, hits.as<float4>(), c->tstats());
-        else hipLaunchKernelGGL(k_trace_rays<false>, dim3(grid_for(c, n, 6)), dim3(kBlock), 0, c->stream, c->sd, ro.as<float4>(), rd.as<float4>(), n, shadow, hits.as<float4>(), c->tstats());
+        if (count) hipLaunchKernelGGL(k_trace_rays<true>, dim3(grid_for(c, n, kTraceBlocksPerCu)), dim3(kBlock), 0, c->stream, c->sd, ro.as<float4>(), rd.as<float4>(), n, shadow, hits.as<float4>(), RT_CURSOR(c->aux_cursor()), c->tstats());
+        else hipLaunchKernelGGL(k_trace_rays<false>, dim3(grid_for(c, n, kTraceBlocksPerCu)), dim3(kBlock), 0, c->stream, c->sd, ro.as<float4>(), rd.as<float4>(), n, shadow, hits.as<float4>(), RT_CURSOR(c->aux_cursor()), c->tstats());
     }
     end_call(c);
     HIPCHK(c, hipGetLastError());
@@ -668,7 +679,8 @@ extern "C" int rt_bench_trace(rt_ctx* c, uint32_t n, const float* origins, const
     HIPCHK(c, hipEventCreate(&a));
     HIPCHK(c, hipEventCreate(&b));
     auto launch = [&] {
-        hipLaunchKernelGGL(k_trace_rays<false>, dim3(grid_for(c, n, 6)), dim3(kBlock), 0, c->stream, c->sd, ro.as<float4>(), rd.as<float4>(), n, shadow, hits.as<float4>(), c->tstats());
+        (void)hipMemsetAsync(c->aux_cursor(), 0, 4, c->stream);
+        hipLaunchKernelGGL(k_trace_rays<false>, dim3(grid_for(c, n, kTraceBlocksPerCu)), dim3(kBlock), 0, c->stream, c->sd, ro.as<float4>(), rd.as<float4>(), n, shadow, hits.as<float4>(), RT_CURSOR(c->aux_cursor()), c->tstats());
     };
     launch();  // warm-up
     (void)hipEventRecord(a, c->stream);

@@ -16,7 +16,19 @@
 namespace rtdev {
 
 constexpr uint32_t kBlock = 256;          // 4 wavefronts per workgroup
-constexpr uint32_t kStackLds = 24;        // traversal stack entries kept in LDS per lane (24 KiB per workgroup)
+#ifndef RT_STACK_LDS
+#define RT_STACK_LDS 24
+#endif
+#ifndef RT_REFILL_AT
+#define RT_REFILL_AT 16
+#endif
+#ifndef RT_CHUNK
+#define RT_CHUNK 256
+#endif
+#ifndef RT_LEAF_BATCH
+#define RT_LEAF_BATCH 16
+#endif
+constexpr uint32_t kStackLds = RT_STACK_LDS;  // traversal stack entries kept in LDS per lane (1 KiB per entry per workgroup)
 constexpr uint32_t kStackMax = 65;        // MAX_BVH_DEPTH + 1, main.comp:6 / intersects.comp:130
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kRefNone = 0x7FFFFFFFu;
@@ -77,75 +89,187 @@ RT_DEV uint32_t wave_sum(uint32_t v) {
 }
 
 // ---- traversal -----------------------------------------------------------------------------------------
-// Closest hit with t < best_t on entry. Visit order and tie rules are those of hit_meshes
-// (intersects.comp:124-175): the nearer child first, on equal entry distance the right child first, a child
-// is entered only while its entry distance is strictly below the current hit distance, triangles of a leaf in
-// storage order with a strict "closer" test, so the first triangle tested wins an exact tie.
-// `stack` points at this lane's column of the workgroup's LDS stack (stride kBlock words).
-template <bool COUNT>
-RT_DEV void closest_hit(const SceneDev& sc, f3 o, f3 d, float& best_t, float& best_u, float& best_v, uint32_t& best_prim,
-                        uint32_t* stack, uint32_t& n_node, uint32_t& n_leaf, uint32_t& n_tri) {
-    uint32_t cur = sc.root_ref;
-    if (cur == kRefNone) return;
-    const f3 inv = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
-    uint32_t sp = 0;
+// Per ray, visit order and tie rules are exactly those of hit_meshes (intersects.comp:124-175): the nearer child
+// first, on equal entry distance the right child first, a child is entered only while its entry distance is
+// strictly below the current hit distance, triangles of a leaf in storage order with a strict "closer" test, so the
+// first triangle tested wins an exact tie. Only the scheduling across the 64 lanes differs from a per-thread loop:
+//
+//   * persistent wavefronts pull rays from a device-side cursor and refill lanes whose ray has finished, so a wave
+//     is not held hostage by its slowest ray;
+//   * "while-while": all lanes first walk interior nodes until every live lane is parked on a leaf (or done), then
+//     the parked leaves are intersected together. Box tests and triangle tests are therefore each executed with
+//     most lanes active instead of being serialised inside every iteration.
+//
+// The traversal stack keeps its first kStackLds entries per lane in LDS (entry-major, so lanes never conflict on a
+// bank) and the rest, up to the reference's bound of 65, in per-lane scratch.
+
+constexpr uint32_t kDone = 0x7FFFFFFEu;       // lane has no node to visit
+
+struct LaneRay {
+    f3 o, d, inv;
+    float t, u, v;
+    uint32_t prim;
+    uint32_t cur;        // node record index, leaf reference, or kDone
+    uint32_t sp;
+    uint32_t item;       // index of the work item this lane is tracing
+};
+
+// The LDS part of the stack is addressed through an explicit LDS pointer type so pushes and pops stay ds_write /
+// ds_read; with generic pointers the compiler folds the LDS and scratch cases into one flat access whose
+// completion every iteration then has to wait for.
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+
+RT_DEV void stack_push(lds_u32* stack, uint32_t* spill, uint32_t& sp, uint32_t ref) {
+    if (__builtin_expect(sp < kStackLds, 1)) stack[sp * kBlock] = ref;
+    else spill[sp - kStackLds] = ref;
+    ++sp;
+}
+RT_DEV uint32_t stack_pop(const lds_u32* stack, const uint32_t* spill, uint32_t& sp) {
+    if (sp == 0) return kDone;
+    --sp;
+    if (__builtin_expect(sp < kStackLds, 1)) return stack[sp * kBlock];
+    return spill[sp - kStackLds];
+}
+
+// One interior-node visit: slab test of both children (intersects.comp:103-121), ordered descent.
+RT_DEV void node_step(const SceneDev& sc, LaneRay& r, lds_u32* stack, uint32_t* spill) {
+    const float4* np = sc.nodes + size_t(r.cur) * 4;
+    float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+    f3 l1 = (f3{q0.x, q0.y, q0.z} - r.o) * r.inv, l2 = (f3{q0.w, q1.x, q1.y} - r.o) * r.inv;
+    f3 r1 = (f3{q1.z, q1.w, q2.x} - r.o) * r.inv, r2 = (f3{q2.y, q2.z, q2.w} - r.o) * r.inv;
+    float l_lo = fmaxf(fmaxf(fminf(l1.x, l2.x), fminf(l1.y, l2.y)), fminf(l1.z, l2.z));
+    float l_hi = fminf(fminf(fmaxf(l1.x, l2.x), fmaxf(l1.y, l2.y)), fmaxf(l1.z, l2.z));
+    float r_lo = fmaxf(fmaxf(fminf(r1.x, r2.x), fminf(r1.y, r2.y)), fminf(r1.z, r2.z));
+    float r_hi = fminf(fminf(fmaxf(r1.x, r2.x), fmaxf(r1.y, r2.y)), fmaxf(r1.z, r2.z));
+    float dl = (l_lo <= l_hi && l_hi > 0.0f) ? l_lo : INFINITY;
+    float dr = (r_lo <= r_hi && r_hi > 0.0f) ? r_lo : INFINITY;
+    uint32_t ref_l = __float_as_uint(q3.x), ref_r = __float_as_uint(q3.y);
+    bool go_l = dl < r.t, go_r = dr < r.t;
+    bool left_first = dl < dr;
+    uint32_t near_ref = left_first ? ref_l : ref_r, far_ref = left_first ? ref_r : ref_l;
+    bool go_near = left_first ? go_l : go_r, go_far = left_first ? go_r : go_l;
+    if (go_near) {
+        if (go_far) stack_push(stack, spill, r.sp, far_ref);
+        r.cur = near_ref;
+    } else if (go_far) {
+        r.cur = far_ref;
+    } else {
+        r.cur = stack_pop(stack, spill, r.sp);
+    }
+}
+
+// Moeller-Trumbore exactly as hit_triangle evaluates it (intersects.comp:37-64) on the 48-byte record
+// {v0, n.x} {v1-v0, n.y} {v2-v0, n.z}.
+RT_DEV void triangle_test(const SceneDev& sc, LaneRay& r, uint32_t tri) {
+    const float4* tp = sc.isect + size_t(tri) * 3;
+    float4 A = tp[0], B = tp[1], C = tp[2];        // all 48 bytes requested at once: one round trip per triangle
+    f3 pn = {A.w, B.w, C.w};
+    float ndd = dot(pn, r.d);
+    f3 ab = xyz(B), ac = xyz(C);
+    f3 oo = r.o - xyz(A);
+    f3 p = cross(r.d, ac);
+    f3 q = cross(oo, ab);
+    float inv_det = 1.0f / dot(p, ab);
+    float t = dot(q, ac) * inv_det;
+    float u = dot(p, oo) * inv_det;
+    float v = dot(q, r.d) * inv_det;
+    float w = 1.0f - u - v;
+    // the shader's chain of early returns (intersects.comp:42,52,61), evaluated without branches; every comparison is
+    // written exactly as there, so NaNs fall through the same way
+    bool reject = (fabsf(ndd) < kRayEps) | (t < kRayEps) | (u < 0.0f) | (v < 0.0f) | (w < 0.0f) | (u > 1.0f) | (v > 1.0f) | (w > 1.0f);
+    bool take = !reject & (t < r.t);
+    r.t = take ? t : r.t;
+    r.u = take ? u : r.u;
+    r.v = take ? v : r.v;
+    r.prim = take ? tri : r.prim;
+}
+
+// Work description for the persistent tracer: how item i becomes a ray and where its result goes.
+//   bool load(uint32_t i, f3& o, f3& d, float& tmax)      -- tmax is the initial "closest so far"
+//   void store(uint32_t i, const LaneRay& r)
+template <bool COUNT, class Work>
+RT_DEV void trace_persistent(const SceneDev& sc, const Work& work, uint32_t n, uint32_t* cursor, lds_u32* stack,
+                             uint32_t& n_node, uint32_t& n_leaf, uint32_t& n_tri) {
+    constexpr uint32_t kRefillAt = RT_REFILL_AT;     // refill once this many lanes sit idle
+    // consecutive work items a wave owns at a time: RT_CHUNK when there is plenty of work, down to 64 when the queue is
+    // short (late bounces), so every resident wave still gets a share
+    const uint32_t waves_total = (gridDim.x * kBlock) >> 6;
+    uint32_t kChunk = ((n / waves_total) + 63u) & ~63u;
+    kChunk = kChunk < 64u ? 64u : (kChunk > RT_CHUNK ? RT_CHUNK : kChunk);
+    constexpr uint32_t kLeafBatch = RT_LEAF_BATCH;   // intersect parked leaves once this many lanes wait on one
     uint32_t spill[kStackMax - kStackLds];
+    LaneRay r;
+    r.cur = kDone; r.sp = 0; r.item = 0; r.prim = kNoPrim; r.t = INFINITY; r.u = r.v = 0.0f;
+    r.o = r.d = r.inv = f3{0.0f, 0.0f, 0.0f};
+    bool live = false;
+    bool drained = false;       // wave-uniform: the cursor has passed the end of the work list
+    const uint32_t lane = lane_id();
+    // Work is handed out in chunks of kChunk consecutive items (neighbouring pixels / queue entries): a wave refills its
+    // idle lanes from its current chunk, so the rays it holds stay spatially close, and takes a new chunk from the
+    // device-wide cursor only when the current one is used up (or, without a cursor, from a block-strided sequence).
+    uint32_t chunk_pos = 0, chunk_end = 0;                                   // wave-uniform
+    uint32_t next_static = ((blockIdx.x * kBlock + threadIdx.x) >> 6) * kChunk;
+    const uint32_t static_stride = (gridDim.x * kBlock >> 6) * kChunk;
     for (;;) {
-        if (cur & kLeafBit) {
+        unsigned long long idle = __ballot(!live);
+        uint32_t n_idle = uint32_t(__popcll(idle));
+        if (!drained && n_idle >= kRefillAt) {
+            if (chunk_pos >= chunk_end) {
+                uint32_t base = 0;
+                if (cursor) {
+                    if (lane == 0) base = atomicAdd(cursor, kChunk);
+                    base = __shfl(base, 0);
+                } else {
+                    base = next_static;
+                    next_static += static_stride;
+                }
+                chunk_pos = base;
+                chunk_end = base + kChunk < n ? base + kChunk : n;
+                if (base >= n) { drained = true; chunk_pos = chunk_end = 0; }
+            }
+            uint32_t avail = chunk_end - chunk_pos;
+            uint32_t rank = uint32_t(__popcll(idle & ((1ull << lane) - 1ull)));
+            if (!live && rank < avail) {
+                uint32_t mine = chunk_pos + rank;
+                float tmax;
+                work.load(mine, r.o, r.d, tmax);
+                r.inv = f3{1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z};
+                r.t = tmax; r.u = 0.0f; r.v = 0.0f; r.prim = kNoPrim;
+                r.item = mine; r.sp = 0;
+                r.cur = sc.root_ref == kRefNone ? kDone : sc.root_ref;
+                live = true;
+            }
+            chunk_pos += n_idle < avail ? n_idle : avail;
+        }
+        if (!__any(live)) {
+            if (drained) break;
+            continue;
+        }
+        // phase A: interior nodes, until enough lanes are parked on a leaf (or no lane has a node left)
+        for (;;) {
+            bool at_node = live && r.cur < kDone;
+            if (!__any(at_node)) break;
+            if (uint32_t(__popcll(__ballot(live && (r.cur & kLeafBit) != 0u))) >= kLeafBatch) break;
+            if (at_node) {
+                if (COUNT) ++n_node;
+                node_step(sc, r, stack, spill);
+            }
+        }
+        // phase B: the parked leaves
+        if (live && (r.cur & kLeafBit)) {
             if (COUNT) ++n_leaf;
-            uint32_t first = cur & 0x01FFFFFFu;
-            uint32_t count = ((cur >> 25) & 63u) + 1u;
+            uint32_t first = r.cur & 0x01FFFFFFu;
+            uint32_t count = ((r.cur >> 25) & 63u) + 1u;
             for (uint32_t k = 0; k < count; ++k) {
                 if (COUNT) ++n_tri;
-                const float4* tp = sc.isect + size_t(first + k) * 3;
-                float4 A = tp[0], B = tp[1], C = tp[2];
-                f3 pn = {A.w, B.w, C.w};
-                if (fabsf(dot(pn, d)) < kRayEps) continue;       // intersects.comp:42
-                f3 ab = xyz(B), ac = xyz(C);
-                f3 oo = o - xyz(A);
-                f3 p = cross(d, ac);
-                f3 q = cross(oo, ab);
-                float inv_det = 1.0f / dot(p, ab);
-                float t = dot(q, ac) * inv_det;
-                if (t < kRayEps) continue;                        // :52
-                float u = dot(p, oo) * inv_det;
-                float v = dot(q, d) * inv_det;
-                float w = 1.0f - u - v;
-                if (u < 0.0f || v < 0.0f || w < 0.0f || u > 1.0f || v > 1.0f || w > 1.0f) continue;  // :61
-                if (t < best_t) { best_t = t; best_u = u; best_v = v; best_prim = first + k; }
+                triangle_test(sc, r, first + k);
             }
-        } else {
-            if (COUNT) ++n_node;
-            const float4* np = sc.nodes + size_t(cur) * 4;
-            float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
-            // slab test per child, intersects.comp:103-121
-            f3 l1 = (f3{q0.x, q0.y, q0.z} - o) * inv, l2 = (f3{q0.w, q1.x, q1.y} - o) * inv;
-            f3 r1 = (f3{q1.z, q1.w, q2.x} - o) * inv, r2 = (f3{q2.y, q2.z, q2.w} - o) * inv;
-            float l_lo = fmaxf(fmaxf(fminf(l1.x, l2.x), fminf(l1.y, l2.y)), fminf(l1.z, l2.z));
-            float l_hi = fminf(fminf(fmaxf(l1.x, l2.x), fmaxf(l1.y, l2.y)), fmaxf(l1.z, l2.z));
-            float r_lo = fmaxf(fmaxf(fminf(r1.x, r2.x), fminf(r1.y, r2.y)), fminf(r1.z, r2.z));
-            float r_hi = fminf(fminf(fmaxf(r1.x, r2.x), fmaxf(r1.y, r2.y)), fmaxf(r1.z, r2.z));
-            float dl = (l_lo <= l_hi && l_hi > 0.0f) ? l_lo : INFINITY;
-            float dr = (r_lo <= r_hi && r_hi > 0.0f) ? r_lo : INFINITY;
-            uint32_t ref_l = __float_as_uint(q3.x), ref_r = __float_as_uint(q3.y);
-            bool go_l = dl < best_t, go_r = dr < best_t;
-            bool left_first = dl < dr;
-            uint32_t near_ref = left_first ? ref_l : ref_r, far_ref = left_first ? ref_r : ref_l;
-            bool go_near = left_first ? go_l : go_r, go_far = left_first ? go_r : go_l;
-            if (go_near) {
-                if (go_far) {
-                    if (sp < kStackLds) stack[sp * kBlock] = far_ref;
-                    else spill[sp - kStackLds] = far_ref;
-                    ++sp;
-                }
-                cur = near_ref;
-                continue;
-            }
-            if (go_far) { cur = far_ref; continue; }
+            r.cur = stack_pop(stack, spill, r.sp);
         }
-        if (sp == 0) break;
-        --sp;
-        cur = sp < kStackLds ? stack[sp * kBlock] : spill[sp - kStackLds];
+        if (live && r.cur == kDone) {
+            work.store(r.item, r);
+            live = false;
+        }
     }
 }
 
@@ -196,64 +320,81 @@ __global__ __launch_bounds__(kBlock) void k_raygen(rt_camera cam, PathDev pd, ui
     }
 }
 
-// extend: closest hit for every queued slot. queue == nullptr means the identity queue (bounce 0).
-template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_extend(SceneDev sc, PathDev pd, const uint32_t* __restrict__ queue,
-                                                   const uint32_t* __restrict__ count_ptr, uint32_t count_imm,
-                                                   TraceStats* stats) {
-    __shared__ uint32_t s_stack[kStackLds * kBlock];
-    const uint32_t n = count_ptr ? *count_ptr : count_imm;
-    uint32_t n_node = 0, n_leaf = 0, n_tri = 0;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+struct ExtendWork {
+    PathDev pd;
+    const uint32_t* __restrict__ queue;   // nullptr = identity (bounce 0)
+    RT_DEV void load(uint32_t i, f3& o, f3& d, float& tmax) const {
         uint32_t slot = queue ? queue[i] : i;
-        float4 o4 = pd.ray_o[slot], d4 = pd.ray_d[slot];
-        float t = INFINITY, u = 0.0f, v = 0.0f;
-        uint32_t prim = kNoPrim;
-        closest_hit<COUNT>(sc, xyz(o4), xyz(d4), t, u, v, prim, s_stack + threadIdx.x, n_node, n_leaf, n_tri);
-        pd.hit[slot] = make_float4(t, u, v, __uint_as_float(prim));
+        o = xyz(pd.ray_o[slot]);
+        d = xyz(pd.ray_d[slot]);
+        tmax = INFINITY;
     }
-    if (COUNT) {
-        n_node = wave_sum(n_node); n_leaf = wave_sum(n_leaf); n_tri = wave_sum(n_tri);
-        if (lane_id() == 0) {
-            atomicAdd(&stats->extend_node_pops, (unsigned long long)n_node);
-            atomicAdd(&stats->extend_leaf_pops, (unsigned long long)n_leaf);
-            atomicAdd(&stats->extend_tri_tests, (unsigned long long)n_tri);
+    RT_DEV void store(uint32_t i, const LaneRay& r) const {
+        uint32_t slot = queue ? queue[i] : i;
+        pd.hit[slot] = make_float4(r.t, r.u, r.v, __uint_as_float(r.prim));
+    }
+};
+
+// Occluded = a closest hit nearer than tmax whose material is not glass-like (disney.comp:697-701,
+// intersects.comp:152-154). Each slot owns at most one entry per bounce, so the add needs no atomic.
+struct ConnectWork {
+    SceneDev sc;
+    PathDev pd;
+    ShadowQueue sq;
+    RT_DEV void load(uint32_t i, f3& o, f3& d, float& tmax) const {
+        float4 o4 = sq.o[i];
+        o = xyz(o4);
+        d = xyz(sq.d[i]);
+        tmax = o4.w;
+    }
+    RT_DEV void store(uint32_t i, const LaneRay& r) const {
+        bool blocked = false;
+        if (r.prim != kNoPrim) blocked = (__float_as_uint(sc.shade[size_t(r.prim) * 4 + 3].w) & 0x80000000u) == 0u;
+        if (!blocked) {
+            uint32_t slot = __float_as_uint(sq.d[i].w);
+            float4 c = sq.c[i];
+            float4 a = pd.rad[slot];
+            a.x += c.x; a.y += c.y; a.z += c.z;
+            pd.rad[slot] = a;
         }
+    }
+};
+
+template <bool COUNT>
+RT_DEV void flush_counts(uint32_t n_node, uint32_t n_leaf, uint32_t n_tri, unsigned long long* node, unsigned long long* leaf,
+                         unsigned long long* tri) {
+    if (!COUNT) return;
+    n_node = wave_sum(n_node); n_leaf = wave_sum(n_leaf); n_tri = wave_sum(n_tri);
+    if (lane_id() == 0) {
+        atomicAdd(node, (unsigned long long)n_node);
+        atomicAdd(leaf, (unsigned long long)n_leaf);
+        atomicAdd(tri, (unsigned long long)n_tri);
     }
 }
 
+// extend: closest hit for every queued slot (a persistent grid; `cursor` hands out queue entries).
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_extend(SceneDev sc, PathDev pd, const uint32_t* __restrict__ queue,
+                                                   const uint32_t* __restrict__ count_ptr, uint32_t count_imm,
+                                                   uint32_t* cursor, TraceStats* stats) {
+    __shared__ uint32_t s_stack[kStackLds * kBlock];
+    const uint32_t n = count_ptr ? *count_ptr : count_imm;
+    uint32_t n_node = 0, n_leaf = 0, n_tri = 0;
+    ExtendWork work{pd, queue};
+    trace_persistent<COUNT>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, n_node, n_leaf, n_tri);
+    flush_counts<COUNT>(n_node, n_leaf, n_tri, &stats->extend_node_pops, &stats->extend_leaf_pops, &stats->extend_tri_tests);
+}
+
 // connect: visibility of every queued light sample; adds the pre-weighted contribution when unoccluded.
-// Occluded = a closest hit nearer than tmax whose material is not glass-like (disney.comp:697-701,
-// intersects.comp:152-154). Each slot owns at most one entry per bounce, so the add needs no atomic.
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_connect(SceneDev sc, PathDev pd, ShadowQueue sq,
-                                                    const uint32_t* __restrict__ count_ptr, TraceStats* stats) {
+                                                    const uint32_t* __restrict__ count_ptr, uint32_t* cursor, TraceStats* stats) {
     __shared__ uint32_t s_stack[kStackLds * kBlock];
     const uint32_t n = *count_ptr;
     uint32_t n_node = 0, n_leaf = 0, n_tri = 0;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        float4 o4 = sq.o[i], d4 = sq.d[i];
-        float t = o4.w, u = 0.0f, v = 0.0f;
-        uint32_t prim = kNoPrim;
-        closest_hit<COUNT>(sc, xyz(o4), xyz(d4), t, u, v, prim, s_stack + threadIdx.x, n_node, n_leaf, n_tri);
-        bool blocked = false;
-        if (prim != kNoPrim) blocked = (__float_as_uint(sc.shade[size_t(prim) * 4 + 3].w) & 0x80000000u) == 0u;
-        if (!blocked) {
-            uint32_t slot = __float_as_uint(d4.w);
-            float4 c = sq.c[i];
-            float4 r = pd.rad[slot];
-            r.x += c.x; r.y += c.y; r.z += c.z;
-            pd.rad[slot] = r;
-        }
-    }
-    if (COUNT) {
-        n_node = wave_sum(n_node); n_leaf = wave_sum(n_leaf); n_tri = wave_sum(n_tri);
-        if (lane_id() == 0) {
-            atomicAdd(&stats->shadow_node_pops, (unsigned long long)n_node);
-            atomicAdd(&stats->shadow_leaf_pops, (unsigned long long)n_leaf);
-            atomicAdd(&stats->shadow_tri_tests, (unsigned long long)n_tri);
-        }
-    }
+    ConnectWork work{sc, pd, sq};
+    trace_persistent<COUNT>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, n_node, n_leaf, n_tri);
+    flush_counts<COUNT>(n_node, n_leaf, n_tri, &stats->shadow_node_pops, &stats->shadow_leaf_pops, &stats->shadow_tri_tests);
 }
 
 struct ShadeParams {
@@ -552,8 +693,8 @@ __global__ void k_add_sum(float4* __restrict__ sum, const float4* __restrict__ o
 }
 
 // End of a pass: fold the per-bounce queue lengths into the 64-bit totals and clear them for the next pass.
-__global__ void k_finish_pass(uint32_t* __restrict__ q_count, uint32_t* __restrict__ sh_count, uint32_t n_counts,
-                              uint32_t camera_rays, TraceStats* stats) {
+__global__ void k_finish_pass(uint32_t* __restrict__ q_count, uint32_t* __restrict__ sh_count, uint32_t* __restrict__ cursors,
+                              uint32_t n_counts, uint32_t camera_rays, TraceStats* stats) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         unsigned long long e = camera_rays, s = 0;
         for (uint32_t b = 1; b < n_counts; ++b) e += q_count[b];
@@ -562,35 +703,43 @@ __global__ void k_finish_pass(uint32_t* __restrict__ q_count, uint32_t* __restri
         stats->shadow_rays += s;
         stats->camera_rays += camera_rays;
         for (uint32_t b = 0; b < n_counts; ++b) { q_count[b] = 0; sh_count[b] = 0; }
+        for (uint32_t b = 0; b < 2 * n_counts; ++b) cursors[b] = 0;
     }
 }
 
 // ---- stage-level kernels on caller-supplied inputs -----------------------------------------------------
+struct RayListWork {
+    SceneDev sc;
+    const float4* __restrict__ ro;   // {origin, tmax when shadow}
+    const float4* __restrict__ rd;
+    float4* __restrict__ hits;
+    int shadow;
+    RT_DEV void load(uint32_t i, f3& o, f3& d, float& tmax) const {
+        float4 o4 = ro[i];
+        o = xyz(o4);
+        d = xyz(rd[i]);
+        tmax = shadow ? o4.w : INFINITY;
+    }
+    RT_DEV void store(uint32_t i, const LaneRay& r) const {
+        if (shadow) {
+            bool blocked = r.prim != kNoPrim && (__float_as_uint(sc.shade[size_t(r.prim) * 4 + 3].w) & 0x80000000u) == 0u;
+            hits[i] = make_float4(blocked ? 0.0f : 1.0f, 0.0f, 0.0f, __uint_as_float(r.prim));
+        } else {
+            hits[i] = make_float4(r.t, r.u, r.v, __uint_as_float(r.prim));
+        }
+    }
+};
+
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_trace_rays(SceneDev sc, const float4* __restrict__ ro, const float4* __restrict__ rd,
-                                                       uint32_t n, int shadow, float4* __restrict__ hits, TraceStats* stats) {
+                                                       uint32_t n, int shadow, float4* __restrict__ hits, uint32_t* cursor,
+                                                       TraceStats* stats) {
     __shared__ uint32_t s_stack[kStackLds * kBlock];
     uint32_t n_node = 0, n_leaf = 0, n_tri = 0;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        float4 o4 = ro[i], d4 = rd[i];
-        float t = shadow ? o4.w : INFINITY, u = 0.0f, v = 0.0f;
-        uint32_t prim = kNoPrim;
-        closest_hit<COUNT>(sc, xyz(o4), xyz(d4), t, u, v, prim, s_stack + threadIdx.x, n_node, n_leaf, n_tri);
-        if (shadow) {
-            bool blocked = prim != kNoPrim && (__float_as_uint(sc.shade[size_t(prim) * 4 + 3].w) & 0x80000000u) == 0u;
-            hits[i] = make_float4(blocked ? 0.0f : 1.0f, 0.0f, 0.0f, __uint_as_float(prim));
-        } else {
-            hits[i] = make_float4(t, u, v, __uint_as_float(prim));
-        }
-    }
-    if (COUNT) {
-        n_node = wave_sum(n_node); n_leaf = wave_sum(n_leaf); n_tri = wave_sum(n_tri);
-        if (lane_id() == 0) {
-            atomicAdd(shadow ? &stats->shadow_node_pops : &stats->extend_node_pops, (unsigned long long)n_node);
-            atomicAdd(shadow ? &stats->shadow_leaf_pops : &stats->extend_leaf_pops, (unsigned long long)n_leaf);
-            atomicAdd(shadow ? &stats->shadow_tri_tests : &stats->extend_tri_tests, (unsigned long long)n_tri);
-        }
-    }
+    RayListWork work{sc, ro, rd, hits, shadow};
+    trace_persistent<COUNT>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, n_node, n_leaf, n_tri);
+    if (shadow) flush_counts<COUNT>(n_node, n_leaf, n_tri, &stats->shadow_node_pops, &stats->shadow_leaf_pops, &stats->shadow_tri_tests);
+    else flush_counts<COUNT>(n_node, n_leaf, n_tri, &stats->extend_node_pops, &stats->extend_leaf_pops, &stats->extend_tri_tests);
 }
 
 struct BsdfIo {
