@@ -66,7 +66,8 @@ struct rt_ctx {
     DevBuf nodes, isect, shade, mats, lights, light_tris, cdf, texels, tex_table, sky, srgb;
     SceneDev sd{};
     // paths
-    DevBuf ray_o, ray_d, hit, thr, rad, q0, q1, sq_o, sq_d, sq_c, counts, stats, seeds;
+    DevBuf ray_o, ray_d, hit, thr, rad, q0, q1, sq_o, sq_d, sq_c, sq_q, stage_next, stage_shadow, counts, stats, seeds;
+    uint32_t shard_cap = 0;
     uint32_t slot_cap = 0;
     // output
     DevBuf sum, accum8, fb, scratch;
@@ -80,12 +81,15 @@ struct rt_ctx {
     bool timings_dirty = false;
 
     PathDev pd() const { return PathDev{ray_o.as<float4>(), ray_d.as<float4>(), hit.as<float4>(), thr.as<float4>(), rad.as<float4>()}; }
-    ShadowQueue sq() const { return ShadowQueue{sq_o.as<float4>(), sq_d.as<float4>(), sq_c.as<float4>()}; }
+    ShadowQueue sq() const { return ShadowQueue{sq_o.as<float4>(), sq_d.as<float4>(), sq_c.as<float4>(), sq_q.as<uint32_t>()}; }
     uint32_t* q_count() const { return counts.as<uint32_t>(); }
     uint32_t* sh_count() const { return counts.as<uint32_t>() + (kMaxBounces + 1); }
     uint32_t* ext_cursor() const { return counts.as<uint32_t>() + 2 * (kMaxBounces + 1); }   // one work cursor per bounce
     uint32_t* con_cursor() const { return counts.as<uint32_t>() + 3 * (kMaxBounces + 1); }
     uint32_t* aux_cursor() const { return counts.as<uint32_t>() + 4 * (kMaxBounces + 1); }   // stage-level entry points
+    // per bounce: kQueueShards append counters for the next-bounce queue, then kQueueShards for the shadow queue
+    uint32_t* shard_counts(uint32_t bounce) const { return counts.as<uint32_t>() + 4 * (kMaxBounces + 1) + 4 + bounce * 2 * kQueueShards; }
+    size_t counts_words() const { return 4 * (kMaxBounces + 1) + 4 + size_t(kMaxBounces) * 2 * kQueueShards; }
     TraceStats* tstats() const { return stats.as<TraceStats>(); }
 };
 
@@ -186,6 +190,11 @@ int alloc_paths(rt_ctx* c) {
     HIPCHK(c, c->thr.ensure(v4));   HIPCHK(c, c->rad.ensure(v4));
     HIPCHK(c, c->q0.ensure(size_t(slots) * 4)); HIPCHK(c, c->q1.ensure(size_t(slots) * 4));
     HIPCHK(c, c->sq_o.ensure(v4)); HIPCHK(c, c->sq_d.ensure(v4)); HIPCHK(c, c->sq_c.ensure(v4));
+    HIPCHK(c, c->sq_q.ensure(size_t(slots) * 4));
+    // staging regions: shard k receives at most ceil(ceil(slots/256)/shards) block-iterations of 256 entries
+    c->shard_cap = uint32_t(((slots + kBlock - 1) / kBlock + kQueueShards - 1) / kQueueShards) * kBlock;
+    HIPCHK(c, c->stage_next.ensure(size_t(c->shard_cap) * kQueueShards * 4));
+    HIPCHK(c, c->stage_shadow.ensure(size_t(c->shard_cap) * kQueueShards * 4));
     HIPCHK(c, c->seeds.ensure(size_t(c->npix) * 4));
     HIPCHK(c, c->sum.ensure(size_t(c->npix) * sizeof(float4)));
     HIPCHK(c, c->accum8.ensure(size_t(c->npix) * 4));
@@ -216,6 +225,7 @@ int run_pass(rt_ctx* c, uint32_t frames, uint32_t frame_first, uint32_t frame_st
     const bool count = (c->flags & RT_COUNT_TRAVERSAL) != 0;
     PathDev pd = c->pd();
     ShadowQueue sq = c->sq();
+    HIPCHK(c, hipMemsetAsync(c->counts.p, 0, c->counts_words() * 4, c->stream));   // queue lengths, cursors, append counters
     {
         StageTimer tm(c, ST_RAYGEN);
         hipLaunchKernelGGL(k_raygen, dim3(grid_for(c, n_slots, 8)), dim3(kBlock), 0, c->stream, c->cam, pd, c->npix, n_slots,
@@ -234,13 +244,23 @@ int run_pass(rt_ctx* c, uint32_t frames, uint32_t frame_first, uint32_t frame_st
         }
         {
             StageTimer tm(c, ST_SHADE);
-            ShadeParams sp{b, c->max_bounces, c->flags, in_q, in_n, n_slots, queues[(b + 1) & 1], c->q_count() + b + 1, c->sh_count() + b};
-            hipLaunchKernelGGL(k_shade, dim3(shade_grid), dim3(kBlock), 0, c->stream, c->sd, pd, sq, sp);
+            ShadeParams sp{b, c->max_bounces, c->flags, in_q, in_n, n_slots, c->stage_next.as<uint32_t>(), c->shard_counts(b),
+                           c->stage_shadow.as<uint32_t>(), c->shard_counts(b) + kQueueShards, c->shard_cap};
+            if (c->sd.n_mat <= kLdsMats && c->sd.n_emissive <= kLdsLights) hipLaunchKernelGGL(k_shade<true>, dim3(shade_grid), dim3(kBlock), 0, c->stream, c->sd, pd, sq, sp);
+            else hipLaunchKernelGGL(k_shade<false>, dim3(shade_grid), dim3(kBlock), 0, c->stream, c->sd, pd, sq, sp);
+        }
+        {
+            StageTimer tm(c, ST_SHADE);
+            const uint32_t per_shard = 4;
+            hipLaunchKernelGGL(k_compact_queues, dim3(kQueueShards * per_shard), dim3(kBlock), 0, c->stream, c->stage_next.as<uint32_t>(),
+                               c->shard_counts(b), queues[(b + 1) & 1], c->q_count() + b + 1, c->stage_shadow.as<uint32_t>(),
+                               c->shard_counts(b) + kQueueShards, c->sq_q.as<uint32_t>(), c->sh_count() + b, c->shard_cap, per_shard);
         }
         if (c->sd.n_light + c->sd.n_emissive != 0) {
             StageTimer tm(c, ST_CONNECT);
-            if (count) hipLaunchKernelGGL(k_connect<true>, dim3(trace_grid), dim3(kBlock), 0, c->stream, c->sd, pd, sq, c->sh_count() + b, RT_CURSOR(c->con_cursor() + b), c->tstats());
-            else hipLaunchKernelGGL(k_connect<false>, dim3(trace_grid), dim3(kBlock), 0, c->stream, c->sd, pd, sq, c->sh_count() + b, RT_CURSOR(c->con_cursor() + b), c->tstats());
+            const bool any = c->sd.has_glass == 0;
+            auto kern = count ? (any ? k_connect<true, true> : k_connect<true, false>) : (any ? k_connect<false, true> : k_connect<false, false>);
+            hipLaunchKernelGGL(kern, dim3(trace_grid), dim3(kBlock), 0, c->stream, c->sd, pd, sq, c->sh_count() + b, RT_CURSOR(c->con_cursor() + b), c->tstats());
         }
     }
     HIPCHK(c, hipGetLastError());
@@ -300,7 +320,7 @@ extern "C" int rt_create(const rt_config* cfg, rt_ctx** out) {
     if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) c->n_cu = std::max(1, prop.multiProcessorCount);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return bail(RT_ERR_DEVICE); }
     if ((rc = alloc_paths(c)) != RT_OK) return bail(rc);
-    if (c->counts.ensure(sizeof(uint32_t) * (4 * (kMaxBounces + 1) + 4)) != hipSuccess || c->stats.ensure(sizeof(TraceStats)) != hipSuccess) {
+    if (c->counts.ensure(sizeof(uint32_t) * c->counts_words()) != hipSuccess || c->stats.ensure(sizeof(TraceStats)) != hipSuccess) {
         c->err = "counter allocation failed"; return bail(RT_ERR_OOM);
     }
     (void)hipMemsetAsync(c->counts.p, 0, c->counts.bytes, c->stream);
@@ -390,7 +410,9 @@ extern "C" int rt_upload_scene(rt_ctx* c, const void* blob, const uint64_t sizes
     sd.nodes = c->nodes.as<float4>(); sd.isect = c->isect.as<float4>(); sd.shade = c->shade.as<float4>();
     sd.mats = c->mats.as<float4>(); sd.lights = c->lights.as<float4>(); sd.light_tris = c->light_tris.as<float4>();
     sd.cdf = c->cdf.as<float>();
-    sd.root_ref = gs.root_ref; sd.n_tri = n_tri; sd.n_light = n_light; sd.n_emissive = n_emissive;
+    sd.has_glass = 0;
+    for (uint32_t i = 0; i < n_mat; ++i) sd.has_glass |= mats[i].spec_trans > 0.5f ? 1u : 0u;
+    sd.root_ref = gs.root_ref; sd.n_tri = n_tri; sd.n_light = n_light; sd.n_emissive = n_emissive; sd.n_mat = n_mat;
     // The shader sizes the CDF from its 16-byte padded binding; an empty table is bound as one dummy word
     // (src/vulkan/path_tracer/descriptors.rs:85-93).
     uint32_t seen = n_emissive;

@@ -55,9 +55,7 @@ struct Mat {
     float metallic, roughness, subsurface, specular_tint, sheen, sheen_tint, clearcoat, clearcoat_roughness, spec_trans, ior;
     uint32_t base_tex, mr_tex, normal_tex, emission_tex;
 };
-RT_DEV Mat load_material(const float4* __restrict__ mats, uint32_t idx) {
-    const float4* p = mats + size_t(idx) * 6;
-    float4 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4], f = p[5];
+RT_DEV Mat unpack_material(float4 a, float4 b, float4 c, float4 d, float4 e, float4 f) {
     Mat m;
     m.base = {a.x, a.y, a.z};
     m.emission = {b.x, b.y, b.z};
@@ -68,6 +66,16 @@ RT_DEV Mat load_material(const float4* __restrict__ mats, uint32_t idx) {
     m.normal_tex = __float_as_uint(f.z); m.emission_tex = __float_as_uint(f.w);
     return m;
 }
+RT_DEV Mat load_material(const float4* __restrict__ mats, uint32_t idx) {
+    const float4* p = mats + size_t(idx) * 6;
+    return unpack_material(p[0], p[1], p[2], p[3], p[4], p[5]);
+}
+
+// LDS-resident copies of small scene tables are read through explicit LDS pointer types (ds_read_b128 / ds_read_b32).
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4f lds_v4f;
+typedef __attribute__((address_space(3))) float lds_f32;
+RT_DEV float4 lds_load4(const lds_v4f* p) { v4f v = *p; return make_float4(v.x, v.y, v.z, v.w); }
 
 // ---- textures: RGBA8 holding sRGB values, bilinear, one mip (image.rs:307-318, sampler.rs:10-34)
 struct TexView {

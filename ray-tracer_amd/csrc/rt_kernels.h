@@ -17,10 +17,13 @@ namespace rtdev {
 
 constexpr uint32_t kBlock = 256;          // 4 wavefronts per workgroup
 #ifndef RT_STACK_LDS
-#define RT_STACK_LDS 24
+#define RT_STACK_LDS 16
 #endif
 #ifndef RT_REFILL_AT
 #define RT_REFILL_AT 16
+#endif
+#ifndef RT_SHADE_WAVES
+#define RT_SHADE_WAVES 1
 #endif
 #ifndef RT_CHUNK
 #define RT_CHUNK 256
@@ -43,7 +46,8 @@ struct SceneDev {
     const float4* __restrict__ lights;    // 3 x float4 per analytic light
     const float4* __restrict__ light_tris; // per emissive triangle: {v0, area} {v1, Le.r} {v2, Le.g} {unit normal, Le.b}
     const float* __restrict__ cdf;        // un-normalised running power
-    uint32_t root_ref, n_tri, n_light, n_emissive;
+    uint32_t root_ref, n_tri, n_light, n_emissive, n_mat;
+    uint32_t has_glass;                   // any material with spec_trans > 0.5 (decides how shadow rays may terminate)
     uint32_t cdf_len_seen;                // length the light selector searches (true length unless the padded-length quirk is on)
     TexView tex;
 };
@@ -56,10 +60,11 @@ struct PathDev {
     float4* __restrict__ rad;     // {radiance rgb, RNG state bits}
 };
 
-struct ShadowQueue {
+struct ShadowQueue {              // light-sample rays, stored at the slot of the path that spawned them
     float4* __restrict__ o;       // {origin, tmax}
-    float4* __restrict__ d;       // {direction, slot bits}
+    float4* __restrict__ d;       // {direction, -}
     float4* __restrict__ c;       // {contribution if unoccluded, -}
+    const uint32_t* __restrict__ queue;   // dense list of slots that have a pending light sample this bounce
 };
 
 struct TraceStats {               // all 64-bit, updated with one atomic per wavefront
@@ -186,8 +191,9 @@ RT_DEV void triangle_test(const SceneDev& sc, LaneRay& r, uint32_t tri) {
 
 // Work description for the persistent tracer: how item i becomes a ray and where its result goes.
 //   bool load(uint32_t i, f3& o, f3& d, float& tmax)      -- tmax is the initial "closest so far"
+// ANYHIT turns the closest-hit search into an occlusion query (stop at the first hit below tmax).
 //   void store(uint32_t i, const LaneRay& r)
-template <bool COUNT, class Work>
+template <bool COUNT, bool ANYHIT, class Work>
 RT_DEV void trace_persistent(const SceneDev& sc, const Work& work, uint32_t n, uint32_t* cursor, lds_u32* stack,
                              uint32_t& n_node, uint32_t& n_leaf, uint32_t& n_tri) {
     constexpr uint32_t kRefillAt = RT_REFILL_AT;     // refill once this many lanes sit idle
@@ -263,8 +269,11 @@ RT_DEV void trace_persistent(const SceneDev& sc, const Work& work, uint32_t n, u
             for (uint32_t k = 0; k < count; ++k) {
                 if (COUNT) ++n_tri;
                 triangle_test(sc, r, first + k);
+                if (ANYHIT && r.prim != kNoPrim) break;
             }
-            r.cur = stack_pop(stack, spill, r.sp);
+            // ANYHIT: the caller only asks whether anything lies nearer than the initial distance, so the first hit ends the ray
+            if (ANYHIT && r.prim != kNoPrim) { r.cur = kDone; r.sp = 0; }
+            else r.cur = stack_pop(stack, spill, r.sp);
         }
         if (live && r.cur == kDone) {
             work.store(r.item, r);
@@ -342,17 +351,18 @@ struct ConnectWork {
     PathDev pd;
     ShadowQueue sq;
     RT_DEV void load(uint32_t i, f3& o, f3& d, float& tmax) const {
-        float4 o4 = sq.o[i];
+        uint32_t slot = sq.queue[i];
+        float4 o4 = sq.o[slot];
         o = xyz(o4);
-        d = xyz(sq.d[i]);
+        d = xyz(sq.d[slot]);
         tmax = o4.w;
     }
     RT_DEV void store(uint32_t i, const LaneRay& r) const {
         bool blocked = false;
         if (r.prim != kNoPrim) blocked = (__float_as_uint(sc.shade[size_t(r.prim) * 4 + 3].w) & 0x80000000u) == 0u;
         if (!blocked) {
-            uint32_t slot = __float_as_uint(sq.d[i].w);
-            float4 c = sq.c[i];
+            uint32_t slot = sq.queue[i];
+            float4 c = sq.c[slot];
             float4 a = pd.rad[slot];
             a.x += c.x; a.y += c.y; a.z += c.z;
             pd.rad[slot] = a;
@@ -381,19 +391,21 @@ __global__ __launch_bounds__(kBlock) void k_extend(SceneDev sc, PathDev pd, cons
     const uint32_t n = count_ptr ? *count_ptr : count_imm;
     uint32_t n_node = 0, n_leaf = 0, n_tri = 0;
     ExtendWork work{pd, queue};
-    trace_persistent<COUNT>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, n_node, n_leaf, n_tri);
+    trace_persistent<COUNT, false>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, n_node, n_leaf, n_tri);
     flush_counts<COUNT>(n_node, n_leaf, n_tri, &stats->extend_node_pops, &stats->extend_leaf_pops, &stats->extend_tri_tests);
 }
 
 // connect: visibility of every queued light sample; adds the pre-weighted contribution when unoccluded.
-template <bool COUNT>
+// When no material of the scene is glass-like (spec_trans > 0.5) "the closest hit is opaque" is the same predicate as
+// "there is a hit", so the query stops at the first hit (ANYHIT); with glass present the closest hit decides.
+template <bool COUNT, bool ANYHIT>
 __global__ __launch_bounds__(kBlock) void k_connect(SceneDev sc, PathDev pd, ShadowQueue sq,
                                                     const uint32_t* __restrict__ count_ptr, uint32_t* cursor, TraceStats* stats) {
     __shared__ uint32_t s_stack[kStackLds * kBlock];
     const uint32_t n = *count_ptr;
     uint32_t n_node = 0, n_leaf = 0, n_tri = 0;
     ConnectWork work{sc, pd, sq};
-    trace_persistent<COUNT>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, n_node, n_leaf, n_tri);
+    trace_persistent<COUNT, ANYHIT>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, n_node, n_leaf, n_tri);
     flush_counts<COUNT>(n_node, n_leaf, n_tri, &stats->shadow_node_pops, &stats->shadow_leaf_pops, &stats->shadow_tri_tests);
 }
 
@@ -402,13 +414,39 @@ struct ShadeParams {
     const uint32_t* in_queue;      // nullptr = identity
     const uint32_t* in_count_ptr;  // nullptr = use in_count_imm
     uint32_t in_count_imm;
-    uint32_t* out_queue;
-    uint32_t* out_count;
-    uint32_t* shadow_count;
+    // Survivors and light samples are appended to kQueueShards staging regions of `shard_cap` entries each (region k takes
+    // the work of block-iterations k, k + kQueueShards, ...), each with its own counter: a single append counter would
+    // serialise ~10^5 returning atomics per sample on one word. k_compact_queues then packs the regions densely.
+    uint32_t* next_stage;
+    uint32_t* next_shard_counts;
+    uint32_t* shadow_stage;
+    uint32_t* shadow_shard_counts;
+    uint32_t shard_cap;
 };
 
+constexpr uint32_t kQueueShards = 64;
+
+constexpr uint32_t kLdsMats = 128;     // materials staged in LDS by k_shade<true> (12 KiB)
+constexpr uint32_t kLdsLights = 256;   // emissive triangles (CDF + light table) staged in LDS by k_shade<true> (17 KiB)
+
 // shade: everything ray_color does at one path vertex (main.comp:137-209) except the two traversals.
-__global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, PathDev pd, ShadowQueue sq, ShadeParams sp) {
+// LDS_TABLES: the material table, the light CDF and the light table are small (<= kLdsMats / kLdsLights entries) and are
+// copied into LDS once per workgroup, which removes three dependent global round trips (material fetch, the CDF binary
+// search, the light record) from every vertex. Larger scenes use the same code reading the tables from global memory.
+template <bool LDS_TABLES>
+__global__ __launch_bounds__(kBlock, RT_SHADE_WAVES) void k_shade(SceneDev sc, PathDev pd, ShadowQueue sq, ShadeParams sp) {
+    __shared__ v4f s_mats[LDS_TABLES ? kLdsMats * 6 : 1];
+    __shared__ v4f s_lt[LDS_TABLES ? kLdsLights * 4 : 1];
+    __shared__ float s_cdf[LDS_TABLES ? kLdsLights : 1];
+    if (LDS_TABLES) {
+        for (uint32_t k = threadIdx.x; k < sc.n_mat * 6; k += kBlock) { float4 v = sc.mats[k]; s_mats[k] = v4f{v.x, v.y, v.z, v.w}; }
+        for (uint32_t k = threadIdx.x; k < sc.n_emissive * 4; k += kBlock) { float4 v = sc.light_tris[k]; s_lt[k] = v4f{v.x, v.y, v.z, v.w}; }
+        for (uint32_t k = threadIdx.x; k < sc.n_emissive; k += kBlock) s_cdf[k] = sc.cdf[k];
+        __syncthreads();
+    }
+    const lds_v4f* l_mats = (const lds_v4f*)s_mats;
+    const lds_v4f* l_lt = (const lds_v4f*)s_lt;
+    const lds_f32* l_cdf = (const lds_f32*)s_cdf;
     const uint32_t n = sp.in_count_ptr ? *sp.in_count_ptr : sp.in_count_imm;
     const uint32_t wave_base0 = (blockIdx.x * kBlock + threadIdx.x) & ~63u;
     const uint32_t stride = gridDim.x * kBlock;
@@ -436,7 +474,13 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, PathDev pd, Shado
                 const float4* ap = sc.shade + size_t(prim) * 4;
                 float4 s0 = ap[0], s1 = ap[1], s2 = ap[2], s3 = ap[3];
                 uint32_t matword = __float_as_uint(s3.w);
-                Mat m = load_material(sc.mats, matword & 0x3FFFFFFFu);
+                Mat m;
+                if (LDS_TABLES) {
+                    const lds_v4f* mp = l_mats + (matword & 0x3FFFFFFFu) * 6;
+                    m = unpack_material(lds_load4(mp), lds_load4(mp + 1), lds_load4(mp + 2), lds_load4(mp + 3), lds_load4(mp + 4), lds_load4(mp + 5));
+                } else {
+                    m = load_material(sc.mats, matword & 0x3FFFFFFFu);
+                }
                 f3 untextured_emission = m.emission;
                 f3 ab = xyz(B), ac = xyz(C);
                 f3 pos = ro + rd * t;
@@ -467,7 +511,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, PathDev pd, Shado
                 // emitter hit, MIS against light sampling (main.comp:170-178; MeshLightPdf disney.comp:297-330)
                 float mis = 1.0f;
                 if (sp.bounce > 0 && sc.n_emissive != 0 && num_lights != 0) {
-                    float total_power = sc.cdf[sc.n_emissive - 1];
+                    float total_power = LDS_TABLES ? l_cdf[sc.n_emissive - 1] : sc.cdf[sc.n_emissive - 1];
                     float lum = luminance(untextured_emission);
                     if (total_power > 0.0f && lum > 0.0f) {
                         f3 ln = cross(ab, ac);
@@ -517,7 +561,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, PathDev pd, Shado
                         // SampleMeshCDF (disney.comp:270-288): binary search in the un-normalised CDF
                         float cdf_rand = pcg_next(seed);
                         int len = int(sc.cdf_len_seen);
-                        auto cdf_at = [&](int k) { return uint32_t(k) < sc.n_emissive ? sc.cdf[k] : 0.0f; };
+                        auto cdf_at = [&](int k) { return uint32_t(k) < sc.n_emissive ? (LDS_TABLES ? float(l_cdf[k]) : sc.cdf[k]) : 0.0f; };
                         float total = cdf_at(len - 1);
                         float target = cdf_rand * total;
                         int lo = 0, hi = len - 1;
@@ -532,8 +576,14 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, PathDev pd, Shado
                         float r1 = pcg_next(seed);
                         float r2 = pcg_next(seed);
                         if (uint32_t(lo) < sc.n_emissive) {
-                            const float4* lt = sc.light_tris + size_t(lo) * 4;
-                            float4 L0 = lt[0], L1 = lt[1], L2 = lt[2], L3 = lt[3];
+                            float4 L0, L1, L2, L3;
+                            if (LDS_TABLES) {
+                                const lds_v4f* lt = l_lt + uint32_t(lo) * 4;
+                                L0 = lds_load4(lt); L1 = lds_load4(lt + 1); L2 = lds_load4(lt + 2); L3 = lds_load4(lt + 3);
+                            } else {
+                                const float4* lt = sc.light_tris + size_t(lo) * 4;
+                                L0 = lt[0]; L1 = lt[1]; L2 = lt[2]; L3 = lt[3];
+                            }
                             float sq1 = sqrtf(r1);
                             float bu = 1.0f - sq1, bv = r2 * sq1, bw = 1.0f - bu - bv;
                             f3 lpnt = xyz(L0) * bu + xyz(L1) * bv + xyz(L2) * bw;
@@ -561,7 +611,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, PathDev pd, Shado
                             if (!(contrib.x == 0.0f && contrib.y == 0.0f && contrib.z == 0.0f)) {
                                 want_shadow = true;
                                 sh_o = make_float4(surface.x, surface.y, surface.z, ldist - kSurfEps);
-                                sh_d = make_float4(ldir.x, ldir.y, ldir.z, __uint_as_float(slot));
+                                sh_d = make_float4(ldir.x, ldir.y, ldir.z, 0.0f);
                                 sh_c = make_float4(contrib.x, contrib.y, contrib.z, 0.0f);
                             }
                         }
@@ -596,14 +646,38 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, PathDev pd, Shado
             }
             pd.rad[slot] = make_float4(rad.x, rad.y, rad.z, __uint_as_float(seed));
         }
-        // queue compaction: one atomic per wavefront and queue
-        uint32_t dst = wave_append(alive, sp.out_count);
-        if (alive) sp.out_queue[dst] = slot;
-        uint32_t sdst = wave_append(want_shadow, sp.shadow_count);
-        if (want_shadow) { sq.o[sdst] = sh_o; sq.d[sdst] = sh_d; sq.c[sdst] = sh_c; }
+        // queue append: one atomic per wavefront and queue, spread over kQueueShards counters
+        const uint32_t shard = (base / kBlock) & (kQueueShards - 1u);
+        uint32_t dst = wave_append(alive, sp.next_shard_counts + shard);
+        if (alive) sp.next_stage[shard * sp.shard_cap + dst] = slot;
+        uint32_t sdst = wave_append(want_shadow, sp.shadow_shard_counts + shard);
+        if (want_shadow) {
+            sq.o[slot] = sh_o; sq.d[slot] = sh_d; sq.c[slot] = sh_c;
+            sp.shadow_stage[shard * sp.shard_cap + sdst] = slot;
+        }
     }
 }
 
+
+// Packs the kQueueShards staging regions of both queues into dense queues and publishes their lengths.
+// grid = kQueueShards * per_shard blocks; block (s, m) copies every per_shard-th 256-entry piece of region s.
+__global__ __launch_bounds__(kBlock) void k_compact_queues(const uint32_t* __restrict__ next_stage, const uint32_t* __restrict__ next_counts,
+                                                           uint32_t* __restrict__ next_queue, uint32_t* __restrict__ next_total,
+                                                           const uint32_t* __restrict__ shadow_stage, const uint32_t* __restrict__ shadow_counts,
+                                                           uint32_t* __restrict__ shadow_queue, uint32_t* __restrict__ shadow_total,
+                                                           uint32_t shard_cap, uint32_t per_shard) {
+    const uint32_t s = blockIdx.x / per_shard, m = blockIdx.x % per_shard;
+    for (int q = 0; q < 2; ++q) {
+        const uint32_t* stage = q ? shadow_stage : next_stage;
+        const uint32_t* counts = q ? shadow_counts : next_counts;
+        uint32_t* out = q ? shadow_queue : next_queue;
+        uint32_t prefix = 0;
+        for (uint32_t k = 0; k < s; ++k) prefix += counts[k];
+        const uint32_t cnt = counts[s];
+        for (uint32_t i = m * kBlock + threadIdx.x; i < cnt; i += per_shard * kBlock) out[prefix + i] = stage[size_t(s) * shard_cap + i];
+        if (s == kQueueShards - 1 && m == 0 && threadIdx.x == 0) *(q ? shadow_total : next_total) = prefix + cnt;
+    }
+}
 
 // ---- accumulate / display ------------------------------------------------------------------------------
 RT_DEV f3 suppress_fireflies(f3 c, float max_value) {  // main.comp:114-120
@@ -692,7 +766,8 @@ __global__ void k_add_sum(float4* __restrict__ sum, const float4* __restrict__ o
     }
 }
 
-// End of a pass: fold the per-bounce queue lengths into the 64-bit totals and clear them for the next pass.
+// End of a pass: fold the per-bounce queue lengths into the 64-bit totals (the counters are cleared by a memset
+// at the start of the next pass).
 __global__ void k_finish_pass(uint32_t* __restrict__ q_count, uint32_t* __restrict__ sh_count, uint32_t* __restrict__ cursors,
                               uint32_t n_counts, uint32_t camera_rays, TraceStats* stats) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -702,8 +777,6 @@ __global__ void k_finish_pass(uint32_t* __restrict__ q_count, uint32_t* __restri
         stats->extend_rays += e;
         stats->shadow_rays += s;
         stats->camera_rays += camera_rays;
-        for (uint32_t b = 0; b < n_counts; ++b) { q_count[b] = 0; sh_count[b] = 0; }
-        for (uint32_t b = 0; b < 2 * n_counts; ++b) cursors[b] = 0;
     }
 }
 
@@ -737,7 +810,8 @@ __global__ __launch_bounds__(kBlock) void k_trace_rays(SceneDev sc, const float4
     __shared__ uint32_t s_stack[kStackLds * kBlock];
     uint32_t n_node = 0, n_leaf = 0, n_tri = 0;
     RayListWork work{sc, ro, rd, hits, shadow};
-    trace_persistent<COUNT>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, n_node, n_leaf, n_tri);
+    if (shadow && !sc.has_glass) trace_persistent<COUNT, true>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, n_node, n_leaf, n_tri);
+    else trace_persistent<COUNT, false>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, n_node, n_leaf, n_tri);
     if (shadow) flush_counts<COUNT>(n_node, n_leaf, n_tri, &stats->shadow_node_pops, &stats->shadow_leaf_pops, &stats->shadow_tri_tests);
     else flush_counts<COUNT>(n_node, n_leaf, n_tri, &stats->extend_node_pops, &stats->extend_leaf_pops, &stats->extend_tri_tests);
 }
