@@ -149,15 +149,15 @@ RT_DEV void node_step(const SceneDev& sc, LaneRay& r, lds_u32* stack, uint32_t* 
     float dl = (l_lo <= l_hi && l_hi > 0.0f) ? l_lo : INFINITY;
     float dr = (r_lo <= r_hi && r_hi > 0.0f) ? r_lo : INFINITY;
     uint32_t ref_l = __float_as_uint(q3.x), ref_r = __float_as_uint(q3.y);
-    bool go_l = dl < r.t, go_r = dr < r.t;
+    // intersects.comp:164-170. dl and dr are never NaN, so the child visited first has the smaller-or-equal entry distance
+    // and "far child passes the strict test against the hit distance" implies "near child passes": the shader's four pushes
+    // reduce to {enter near, stack far} / {enter near} / {nothing to enter: pop}.
     bool left_first = dl < dr;
+    float d_near = left_first ? dl : dr, d_far = left_first ? dr : dl;
     uint32_t near_ref = left_first ? ref_l : ref_r, far_ref = left_first ? ref_r : ref_l;
-    bool go_near = left_first ? go_l : go_r, go_far = left_first ? go_r : go_l;
-    if (go_near) {
-        if (go_far) stack_push(stack, spill, r.sp, far_ref);
+    if (d_near < r.t) {
+        if (d_far < r.t) stack_push(stack, spill, r.sp, far_ref);
         r.cur = near_ref;
-    } else if (go_far) {
-        r.cur = far_ref;
     } else {
         r.cur = stack_pop(stack, spill, r.sp);
     }
