@@ -9,10 +9,14 @@ from collections import defaultdict
 
 def short(name):
     n = name.split("(")[0]
-    for k in ("k_extend", "k_connect", "k_shade", "k_raygen", "k_accumulate", "k_finish_pass", "k_trace_rays", "k_tonemap"):
+    for k in ("k_extend", "k_connect", "k_shade", "k_compact_queues", "k_raygen", "k_accumulate", "k_finish_pass", "k_trace_rays", "k_tonemap"):
         if k in n:
-            return k + ("<count>" if "ILb1" in n or "<true>" in name else "")
+            counted = k in ("k_extend", "k_connect", "k_trace_rays") and ("ILb1" in n or "<true" in name)
+            return k + ("<count>" if counted else "")
     return n[-40:]
+
+
+TRAFFIC = {}
 
 
 def main(out):
@@ -46,10 +50,18 @@ def main(out):
                     print(f"    -> wait_any/wave_cycles {a.get('SQ_WAIT_ANY',0)/a['SQ_WAVE_CYCLES']:.3f}  valu_active/wave_cycles {a.get('SQ_ACTIVE_INST_VALU',0)/a['SQ_WAVE_CYCLES']:.3f}"
                           f"  mean waves in flight (wave_cycles/busy_cycles) {a['SQ_WAVE_CYCLES']/max(1,a.get('SQ_BUSY_CYCLES',1)):.2f}")
                 if "FETCH_SIZE" in a:
+                    TRAFFIC.setdefault(k, {})["fetch_kb_per_launch_raw"] = a["FETCH_SIZE"] / max(1, len(calls[k]))
+                    TRAFFIC[k]["launches_fetch_pass"] = len(calls[k])
                     print(f"    -> FETCH_SIZE {a['FETCH_SIZE']:.6g} KB reported; x2 gfx950 correction for wide reads = {2*a['FETCH_SIZE']*1024/1e9:.4f} GB total, {2*a['FETCH_SIZE']*1024/max(1,len(calls[k]))/1e6:.3f} MB/launch")
                 if "WRITE_SIZE" in a:
+                    TRAFFIC.setdefault(k, {})["write_kb_per_launch"] = a["WRITE_SIZE"] / max(1, len(calls[k]))
                     print(f"    -> WRITE_SIZE {a['WRITE_SIZE']*1024/1e9:.4f} GB total, {a['WRITE_SIZE']*1024/max(1,len(calls[k]))/1e6:.3f} MB/launch")
 
 
 if __name__ == "__main__":
     main(sys.argv[1])
+    import json
+    for k, v in TRAFFIC.items():
+        # gfx950: FETCH_SIZE tallies 128-B requests at 64 B -> double it (calibrated for wide streaming reads only)
+        v["hbm_bytes_per_launch"] = (2.0 * v.get("fetch_kb_per_launch_raw", 0.0) + v.get("write_kb_per_launch", 0.0)) * 1024.0
+    json.dump(TRAFFIC, open(os.path.join(sys.argv[1], "traffic.json"), "w"), indent=1)
