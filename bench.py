@@ -82,6 +82,20 @@ def main():
     scene = gen(**kw).finalize()
     t_scene = time.time() - t0
 
+    # BVH build-time baseline (stand-in for the reference's criterion bench, benches/bvh.rs:11-40: clone the triangles,
+    # build, 10 samples): median wall time of the library's binned-SAH builder on this scene, rank 0 only.
+    bvh_bench = None
+    if rank == 0 and not args.no_cpu_baseline:
+        ts = []
+        for _ in range(10):
+            clone = gen(**kw)
+            t1 = time.perf_counter()
+            clone.build_bvh()
+            ts.append((time.perf_counter() - t1) * 1e3)
+        bvh_bench = {"builder": "binned SAH, object splits (BinSah::default parameters)", "triangles": int(len(scene.triangles)),
+                     "median_ms": float(np.median(ts)), "min_ms": float(min(ts)), "samples": 10, "threads": min(64, os.cpu_count() or 1),
+                     "mtris_per_s": len(scene.triangles) / float(np.median(ts)) / 1e3}
+
     r = rt.HipRenderer.create(scene, max_bounces=args.bounces, device=local_rank, frames_per_pass=args.frames_per_pass)
     from ray_tracer_amd.distributed import frame_slice
     r.set_frame_slice(*frame_slice(rank, world))
@@ -149,7 +163,7 @@ def main():
         "value_div_8": rays_total / elapsed / 1e6 / 8.0,
         "extend_rays": ext_total, "shadow_rays": sh_total,
         "mpaths_per_sec": world * args.steps * npix / elapsed / 1e6,
-        "scene_build_s": t_scene, "bvh_build_ms": scene.bvh_stats.get("build_ms"),
+        "scene_build_s": t_scene, "bvh_build_ms": scene.bvh_stats.get("build_ms"), "bvh_build_bench": bvh_bench,
     }
 
     # ---- roofline of the dominant kernel (extend), rank 0 only: HIP-event time per launch, algorithmic bytes from traversal counters
@@ -171,9 +185,19 @@ def main():
         b_con = algorithmic_bytes_connect(c["shadow_rays"], c["shadow_node_pops"], c["shadow_tri_tests"])
         ext_s = tm["extend_ms"] / 1e3
         achieved = b_ext / ext_s / 1e9 if ext_s > 0 else 0.0
+        # HBM-side bytes per launch of the same kernel, from the committed rocprofv3 counter passes of this exact workload
+        # (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; tools/profile_gpu.sh). Counters cannot be read from inside this process.
+        traffic = None
+        tfile = ROOT / "profiles" / "r1_v2_traffic.json"
+        default_cfg = (args.scene == "atrium" and args.scale == 1.0 and (args.width, args.height, args.bounces) == (1920, 1080, 8)
+                       and args.frames_per_pass == 0)
+        if default_cfg and tfile.exists():
+            traffic = json.loads(tfile.read_text()).get("k_extend", {}).get("hbm_bytes_per_launch")
         result["roofline"] = {
             "kernel": "k_extend", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_note": "bytes per launch beyond L2 (Infinity Cache hits included), profiles/r1_v2_traffic.json; algorithmic bytes "
+                            "charge every node visit to HBM, so achieved may exceed the HBM peak when caches serve the BVH",
             "bytes_per_launch": b_ext / max(1, tm["extend_launches"]), "avg_launch_ms": tm["extend_ms"] / max(1, tm["extend_launches"]),
             "launches": tm["extend_launches"], "samples": k,
             "bytes_per_ray": b_ext / max(1, c["extend_rays"]),
@@ -204,7 +228,7 @@ def main():
             crays += cc["rays"] + cc["shadow_rays"]
             frames += 1
             el = time.perf_counter() - t0
-            if el > 12.0 or frames >= 64:
+            if el > 12.0 or frames >= 512:
                 break
         result["cpu_baseline"] = {"value": crays / el / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
                                   "sample": f"{scene.name} at {sw}x{sh} (1/16 of the pixels), {frames} spp, {args.bounces} bounces, {el:.1f} s",

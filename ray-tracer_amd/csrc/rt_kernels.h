@@ -20,7 +20,7 @@ constexpr uint32_t kBlock = 256;          // 4 wavefronts per workgroup
 #define RT_STACK_LDS 16
 #endif
 #ifndef RT_REFILL_AT
-#define RT_REFILL_AT 16
+#define RT_REFILL_AT 24
 #endif
 #ifndef RT_SHADE_WAVES
 #define RT_SHADE_WAVES 1

@@ -332,6 +332,41 @@ def test_absorption_fix_switch(rt, oracle, scene_cache):
     r.destroy()
 
 
+def test_large_material_and_light_tables_use_the_global_memory_path(rt, oracle):
+    """More than 128 materials / 256 emissive triangles: shading reads its tables from global memory instead of the LDS
+    copies, and a glass material forces closest-hit (not first-hit) shadow rays. Same parity bar as everywhere else."""
+    from ray_tracer_amd.scenes import Mesh
+    from ray_tracer_amd.scene import Scene, default_material, look_at_camera
+    rng = np.random.default_rng(31)
+    n_mat = 400
+    mats = default_material(n_mat)
+    mats["base_colour"][:, :3] = rng.uniform(0.2, 0.9, size=(n_mat, 3))
+    mats["roughness"] = rng.uniform(0.2, 1.0, size=n_mat)
+    mats["spec_trans"][5] = 1.0
+    mats["emission"][200:, :3] = rng.uniform(2.0, 6.0, size=(200, 1))
+    mesh = Mesh()
+    mesh.quad([[-6, 0, 6], [6, 0, 6], [6, 0, -6], [-6, 0, -6]], 0)
+    for k in range(320):   # 320 small emissive quads facing down = 640 emissive triangles
+        x, z = rng.uniform(-4, 4, size=2)
+        mesh.quad([[x - 0.1, 3.0, z - 0.1], [x + 0.1, 3.0, z - 0.1], [x + 0.1, 3.0, z + 0.1], [x - 0.1, 3.0, z + 0.1]], 200 + (k % 200))
+    for k in range(150):
+        c = rng.uniform([-4, 0.3, -4], [4, 2.0, 4])
+        mesh.box(c - 0.25, c + 0.25, 1 + (k % 199))
+    cam = look_at_camera(80, 48, (0.0, 2.0, 7.5), (0.0, 1.0, 0.0))
+    sc = Scene(triangles=mesh.triangles(), materials=mats, camera=cam).finalize()
+    assert len(sc.emissive_tris) == 640 and len(sc.materials) == 400
+    r = rt.HipRenderer.create(sc, max_bounces=5)
+    o = oracle.OracleScene(sc)
+    g = r.render_radiance(2)
+    h, oc = o.render_radiance(2, 5)
+    assert rel_close(g, h, 1e-3, 1e-4).all(axis=-1).mean() > 0.985
+    r.reset_counters()
+    r.render_radiance(2)
+    c = r.counters()
+    assert abs(c["extend_rays"] - oc["rays"]) <= 0.003 * oc["rays"] and c["shadow_rays"] > 0.5 * oc["shadow_rays"]
+    r.destroy()
+
+
 # ------------------------------------------------------------------ host semantics (a21) and error behaviour
 def test_frame_counter_and_reset_rules(pair):
     r, _, sc = pair("cornell", {"width": 64, "height": 64})
