@@ -115,6 +115,16 @@ const char* rt_last_error(const rt_ctx* ctx);
 int rt_bvh_build(rt_triangle* tris, uint32_t n_tri, const rt_bvh_params* params,
                  rt_bvh_node* nodes, uint32_t* n_nodes, rt_bvh_stats* stats);
 
+/* The same contract built with spatial splits (SBVH), the policy Scene::build_bvh actually selects
+ * (BinSah::spatial(), src/accelerators/bvh_based/bin_sah.rs:94-100,127-134,862-1450): alpha gates the spatial
+ * candidate on child overlap / root area (reference preset 1e-5), budget_fraction caps duplicated references as a
+ * fraction of n_tri (preset 0.3). Triangles straddling a chosen plane are duplicated, so the leaf-ordered triangles
+ * go to `tris_out` (capacity >= n_tri + floor(n_tri*budget_fraction), must not alias `tris`) and `*n_tris_out` may
+ * exceed n_tri; `nodes` needs 2 * that capacity. The tree does not depend on the thread count. */
+int rt_bvh_build_spatial(const rt_triangle* tris, uint32_t n_tri, const rt_bvh_params* params, float alpha,
+                         float budget_fraction, rt_triangle* tris_out, uint32_t tri_capacity, uint32_t* n_tris_out,
+                         rt_bvh_node* nodes, uint32_t node_capacity, uint32_t* n_nodes, rt_bvh_stats* stats);
+
 /* Emissive-triangle table and un-normalised power CDF, as Scene::build_lights (src/scene/mod.rs:207-270).
  * `emissive` and `cdf` need room for n_tri entries. Call after rt_bvh_build (tri_index refers to leaf order). */
 int rt_build_lights(const rt_triangle* tris, uint32_t n_tri, const rt_material* mats, uint32_t n_mat,

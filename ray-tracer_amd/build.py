@@ -11,7 +11,7 @@ PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
 CSRC = PKG / "csrc"
 OUT = PKG / "librt_hip.so"
-SOURCES = [CSRC / "rt_api.hip", CSRC / "scene_pack.cpp", CSRC / "bvh_build.cpp"]
+SOURCES = [CSRC / "rt_api.hip", CSRC / "scene_pack.cpp", CSRC / "bvh_build.cpp", CSRC / "bvh_sbvh.cpp"]
 HEADERS = [CSRC / "rt_kernels.h", CSRC / "rt_device_math.h", CSRC / "rt_internal.h", ROOT / "include" / "rt_api.h",
            ROOT / "include" / "rt_types.h"]
 # -ffp-contract=off: intersection and shading arithmetic is specified operation by operation (no fused multiply-add),

@@ -70,18 +70,30 @@ class Scene:
     total_power: float = 0.0
     bvh_stats: dict = field(default_factory=dict)
 
-    # Scene::build_bvh (src/scene/mod.rs:84-115): reorders the triangles in place.
-    def build_bvh(self, threads: int = 0, min_leaf: int = 2, max_leaf: int = 8):
+    # Scene::build_bvh (src/scene/mod.rs:84-115): reorders the triangles in place. `spatial=True` selects the
+    # reference's own policy, BinSah::spatial() (bin_sah.rs:94-100,127-134): triangles may then be duplicated.
+    def build_bvh(self, threads: int = 0, min_leaf: int = 2, max_leaf: int = 8, spatial: bool = False,
+                  alpha: float = 1e-5, budget: float = 0.3):
         lib = load_library()
         n = len(self.triangles)
         self.triangles = np.ascontiguousarray(self.triangles)
-        nodes = np.zeros(max(1, 2 * n), dtype=BVH_NODE)
-        n_nodes = C.c_uint32(0)
         params = api.RtBvhParams(1.0, 1.0, min_leaf, max_leaf, threads)
         stats = api.RtBvhStats()
-        check(lib.rt_bvh_build(ptr(self.triangles), n, C.byref(params), ptr(nodes), C.byref(n_nodes), C.byref(stats)))
+        n_nodes = C.c_uint32(0)
+        if spatial:
+            cap = n + int(n * max(budget, 0.0)) + 1
+            out = np.zeros(cap, dtype=TRIANGLE)
+            nodes = np.zeros(2 * cap, dtype=BVH_NODE)
+            n_out = C.c_uint32(0)
+            check(lib.rt_bvh_build_spatial(ptr(self.triangles), n, C.byref(params), alpha, budget, ptr(out), cap,
+                                           C.byref(n_out), ptr(nodes), 2 * cap, C.byref(n_nodes), C.byref(stats)))
+            self.triangles = out[: n_out.value].copy()
+        else:
+            nodes = np.zeros(max(1, 2 * n), dtype=BVH_NODE)
+            check(lib.rt_bvh_build(ptr(self.triangles), n, C.byref(params), ptr(nodes), C.byref(n_nodes), C.byref(stats)))
         self.bvh = nodes[: n_nodes.value].copy()
         self.bvh_stats = stats.as_dict()
+        self.bvh_stats["duplicated_refs"] = len(self.triangles) - n
         return self
 
     # Scene::build_lights (src/scene/mod.rs:207-270); must follow build_bvh.
@@ -121,6 +133,6 @@ class Scene:
                                          ptr(blob), blob.size))
         return blob
 
-    def finalize(self, threads: int = 0):
+    def finalize(self, threads: int = 0, spatial: bool = False):
         """build_bvh + build_lights, the order `Scene::from_new` uses (src/scene/loader.rs:17-18)."""
-        return self.build_bvh(threads=threads).build_lights()
+        return self.build_bvh(threads=threads, spatial=spatial).build_lights()

@@ -32,9 +32,9 @@ def scene_cache():
     from ray_tracer_amd import scenes
     cache = {}
 
-    def get(name, **kw):
-        key = (name, tuple(sorted(kw.items())))
+    def get(name, spatial=False, **kw):
+        key = (name, spatial, tuple(sorted(kw.items())))
         if key not in cache:
-            cache[key] = scenes.GENERATORS[name](**kw).finalize()
+            cache[key] = scenes.GENERATORS[name](**kw).finalize(spatial=spatial)
         return cache[key]
     return get

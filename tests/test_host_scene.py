@@ -59,6 +59,73 @@ def test_bvh_is_independent_of_thread_count():
     assert a.triangles.tobytes() == b.triangles.tobytes()
 
 
+def check_spatial_contract(nodes, tris):
+    """Contract with duplicated references: leaf ranges contiguous in DFS order, child boxes inside the parent, every
+    leaf triangle overlaps its (possibly clipped) leaf box."""
+    next_first, max_depth, n_leaf = 0, 0, 0
+    visited = np.zeros(len(nodes), bool)
+    stack = [(0, 0)]
+    while stack:
+        i, d = stack.pop()
+        assert not visited[i]
+        visited[i] = True
+        max_depth = max(max_depth, d)
+        nd = nodes[i]
+        if nd["amt"] != 0:
+            a, b = int(nd["idx"]), int(nd["idx"]) + int(nd["amt"])
+            assert a == next_first
+            next_first = b
+            n_leaf += 1
+            v = tris["v"][a:b, :, :3]
+            assert (v.min(axis=1) <= nd["max"] + 1e-6).all() and (v.max(axis=1) >= nd["min"] - 1e-6).all()
+        else:
+            l, r = int(nd["idx"]), int(nd["idx"]) + 1
+            assert r < len(nodes)
+            for c in (l, r):
+                assert (nodes[c]["min"] >= nd["min"]).all() and (nodes[c]["max"] <= nd["max"]).all()
+            stack.append((r, d + 1))
+            stack.append((l, d + 1))
+    assert visited.all() and next_first == len(tris) and max_depth <= 64
+    return max_depth, n_leaf
+
+
+@pytest.mark.parametrize("name,kw", [("cornell", {}), ("atrium", {"scale": 0.05}), ("car", {"scale": 0.03})])
+def test_spatial_bvh_contract_and_coverage(name, kw):
+    """BinSah::spatial() twin (bin_sah.rs:862-1450): duplicates stay within the budget, every input triangle survives,
+    nothing new is invented."""
+    src = scenes.GENERATORS[name](**kw)
+    n = len(src.triangles)
+    before = {t.tobytes() for t in src.triangles}
+    sc = src.build_bvh(spatial=True)
+    depth, n_leaf = check_spatial_contract(sc.bvh, sc.triangles)
+    after = {t.tobytes() for t in sc.triangles}
+    assert before == after
+    st = sc.bvh_stats
+    assert 0 <= st["duplicated_refs"] <= int(n * 0.3) and len(sc.triangles) == n + st["duplicated_refs"]
+    assert st["max_depth"] == depth and st["leaf_count"] == n_leaf and st["node_count"] == 2 * n_leaf - 1 == len(sc.bvh)
+    assert st["max_leaf_size"] <= 8
+
+
+def test_spatial_bvh_is_deterministic_and_never_worse_on_long_thin_geometry():
+    a = scenes.atrium(scale=0.1).build_bvh(threads=1, spatial=True)
+    b = scenes.atrium(scale=0.1).build_bvh(threads=8, spatial=True)
+    assert a.bvh.tobytes() == b.bvh.tobytes() and a.triangles.tobytes() == b.triangles.tobytes()
+    # a fan of long diagonal slivers: the textbook case object splits cannot separate
+    rng = np.random.default_rng(3)
+    k = 400
+    base = rng.uniform(-1, 1, (k, 1, 3)).astype(np.float32) * np.float32(0.05)
+    d = np.array([[0, 0, 0], [10, 10, 0.02], [10, 10.05, 0]], np.float32)[None] + base
+    d[:, :, 2] += np.linspace(0, 1, k, dtype=np.float32)[:, None]
+    tris = make_triangles(d, None, None, np.zeros(k))
+    mk = lambda: Scene(tris.copy(), default_material(1), look_at_camera(8, 8, (0, 0, 5), (0, 0, 0)))
+    obj, spa = mk().build_bvh(), mk().build_bvh(spatial=True)
+    assert spa.bvh_stats["duplicated_refs"] > 0
+    assert spa.bvh_stats["sah_cost"] < obj.bvh_stats["sah_cost"]
+    # budget 0 degenerates to object splits over the same decisions
+    zero = mk().build_bvh(spatial=True, budget=0.0)
+    assert zero.bvh_stats["duplicated_refs"] == 0 and len(zero.triangles) == k
+
+
 def test_bvh_permutes_triangles_only():
     sc = scenes.atrium(scale=0.02)
     before = np.sort(sc.triangles.view(np.uint8).reshape(len(sc.triangles), -1).copy().view("V144").ravel())

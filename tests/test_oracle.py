@@ -94,6 +94,28 @@ def test_bvh_traversal_equals_brute_force(oracle, scene_cache, name, kw, n):
     assert cnt["rays"] == n and cnt["tri_tests"] > 0
 
 
+@pytest.mark.parametrize("name,kw,n", [("cornell", {}, 3000), ("atrium", {"scale": 0.02}, 1500)])
+def test_spatial_split_bvh_gives_the_same_distances(oracle, scene_cache, name, kw, n):
+    """Duplicated references change which copy is reported, not the surface hit. Distances are identical except where
+    two coplanar triangles overlap: their t differ by an ulp and a flat node box (entry distance == t up to rounding)
+    may cull one of them under the strict `<` push rule, in either tree."""
+    a_sc, b_sc = scene_cache(name, **kw), scene_cache(name, spatial=True, **kw)
+    a, b = oracle.OracleScene(a_sc), oracle.OracleScene(b_sc)
+    rng = np.random.default_rng(11)
+    lo = a_sc.triangles["v"][..., :3].min(axis=(0, 1))
+    hi = a_sc.triangles["v"][..., :3].max(axis=(0, 1))
+    ro, rd = random_rays(rng, n, lo, hi)
+    ha, _ = a.trace_closest(ro, rd)
+    hb, _ = b.trace_closest(ro, rd)
+    assert (ha["t"] == hb["t"]).mean() > 0.99
+    hit = ha["prim"] != 0xFFFFFFFF
+    assert np.array_equal(hit, hb["prim"] != 0xFFFFFFFF)
+    assert np.allclose(ha["t"][hit], hb["t"][hit], rtol=1e-6, atol=0)
+    ta, tb = a_sc.triangles[ha["prim"][hit]], b_sc.triangles[hb["prim"][hit]]
+    assert (ta["v"] == tb["v"]).all(axis=(1, 2)).mean() > 0.99
+    assert np.array_equal(a.trace_shadow(ro, rd, np.full(n, 5.0, np.float32)), b.trace_shadow(ro, rd, np.full(n, 5.0, np.float32)))
+
+
 def test_shadow_rule_glass_does_not_occlude(oracle):
     """inShadow = closest hit exists, is nearer than tmax, and its material has spec_trans <= 0.5 (intersects.comp:152-154)."""
     cam = look_at_camera(8, 8, (0, 0, 3), (0, 0, 0))
