@@ -44,8 +44,11 @@ enum {
     RT_FIX_ABSORPTION    = 1u << 2, /* Beer-Lambert with the physical sign instead of main.comp:182-184           */
     RT_COUNT_TRAVERSAL   = 1u << 3, /* count node pops / triangle tests (mesh_tests, intersects.comp:136,140)     */
     RT_KERNEL_TIMING     = 1u << 4, /* bracket every kernel launch with events (gpu_timer.rs:18-78 analogue)      */
-    RT_POP_CULL          = 1u << 5  /* drop a stacked subtree whose entry distance no longer beats the hit; may
-                                       change the winner among hits whose distances tie within rounding          */
+    RT_SINGLE_STREAM     = 1u << 5  /* trace one wavefront pass at a time on one stream. By default consecutive
+                                       passes run on two streams so that the ALU-bound traversal of one overlaps
+                                       the memory-bound shading of the other; accumulation order, and therefore
+                                       every output bit, is the same either way. Implied by RT_KERNEL_TIMING so
+                                       that per-kernel times are those of kernels running alone.                 */
 };
 
 typedef struct rt_config {
@@ -59,7 +62,8 @@ typedef struct rt_config {
 
 typedef struct rt_ctx rt_ctx;
 
-/* Per-kernel device time of the last rt_render / rt_trace_* call, valid when RT_KERNEL_TIMING is set.
+/* Per-kernel device time of the last rt_render / rt_trace_* call, valid when RT_KERNEL_TIMING is set
+ * (the context then runs its passes one after another on a single stream).
  * Stands in for VulkanRenderer::last_timer_perf (renderer.rs:239-248). */
 typedef struct rt_timings {
     float    total_ms;        /* whole call, first launch to last                      */

@@ -41,6 +41,7 @@ RT_REF_CDF_PAD = 1 << 1
 RT_FIX_ABSORPTION = 1 << 2
 RT_COUNT_TRAVERSAL = 1 << 3
 RT_KERNEL_TIMING = 1 << 4
+RT_SINGLE_STREAM = 1 << 5
 
 
 class RtConfig(C.Structure):

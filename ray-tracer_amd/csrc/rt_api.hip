@@ -2,13 +2,21 @@
 //
 // A context plays the part of the reference's PathTracer + VulkanRenderer pair
 // (src/vulkan/path_tracer/mod.rs:56-344, src/vulkan/renderer.rs:62-507) without a window: it owns the scene in
-// device layout, the path-state and queue buffers, the fp32 accumulator and one HIP stream on which every
-// kernel of a render call is queued back to back (no host synchronisation inside rt_render).
+// device layout, the path-state and queue buffers, the fp32 accumulator and the HIP streams on which the
+// kernels of a render call are queued back to back (no host synchronisation inside rt_render).
+//
+// Stream plan: wavefront passes alternate between `lanes` (a stream plus a private set of path-state and
+// queue buffers each), so the traversal kernels of one pass, which are bound by vector-ALU issue, share the
+// machine with the shading kernels of the neighbouring pass, which are bound by HBM. Accumulation of every
+// pass is queued on the context's main stream in pass order (it waits on the pass's lane through an event, and
+// the lane's next pass waits until its radiance buffer has been consumed), so the floating-point summation
+// order does not depend on how the lanes interleave.
 
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -44,9 +52,30 @@ struct DevBuf {
 #define RT_CURSOR(p) (RT_DYNAMIC ? (p) : nullptr)
 constexpr uint32_t kTraceBlocksPerCu = 8;   // persistent traversal grid: workgroups per CU (4 waves each)
 
+constexpr uint32_t kMaxLanes = 4;
+
 enum Stage { ST_RAYGEN = 0, ST_EXTEND, ST_SHADE, ST_CONNECT, ST_ACCUM, ST_COUNT };
 
 struct Span { int stage; hipEvent_t a, b; };
+
+// One in-flight wavefront pass: its stream, path state, queues and counters.
+struct Lane {
+    hipStream_t stream = nullptr;
+    DevBuf ray_o, ray_d, hit, thr, rad, q0, q1, sq_o, sq_d, sq_c, sq_q, stage_next, stage_shadow, counts;
+    hipEvent_t pass_done = nullptr, consumed = nullptr;
+    bool busy = false;   // a pass was queued whose radiance the main stream has (or will have) consumed at `consumed`
+
+    PathDev pd() const { return PathDev{ray_o.as<float4>(), ray_d.as<float4>(), hit.as<float4>(), thr.as<float4>(), rad.as<float4>()}; }
+    ShadowQueue sq() const { return ShadowQueue{sq_o.as<float4>(), sq_d.as<float4>(), sq_c.as<float4>(), sq_q.as<uint32_t>()}; }
+    uint32_t* q_count() const { return counts.as<uint32_t>(); }
+    uint32_t* sh_count() const { return counts.as<uint32_t>() + (kMaxBounces + 1); }
+    uint32_t* ext_cursor() const { return counts.as<uint32_t>() + 2 * (kMaxBounces + 1); }   // one work cursor per bounce
+    uint32_t* con_cursor() const { return counts.as<uint32_t>() + 3 * (kMaxBounces + 1); }
+    uint32_t* aux_cursor() const { return counts.as<uint32_t>() + 4 * (kMaxBounces + 1); }   // stage-level entry points
+    // per bounce: kQueueShards append counters for the next-bounce queue, then kQueueShards for the shadow queue
+    uint32_t* shard_counts(uint32_t bounce) const { return counts.as<uint32_t>() + 4 * (kMaxBounces + 1) + 4 + bounce * 2 * kQueueShards; }
+    static size_t counts_words() { return 4 * (kMaxBounces + 1) + 4 + size_t(kMaxBounces) * 2 * kQueueShards; }
+};
 
 }  // namespace
 
@@ -65,8 +94,11 @@ struct rt_ctx {
     // scene
     DevBuf nodes, isect, shade, mats, lights, light_tris, cdf, texels, tex_table, sky, srgb;
     SceneDev sd{};
-    // paths
-    DevBuf ray_o, ray_d, hit, thr, rad, q0, q1, sq_o, sq_d, sq_c, sq_q, stage_next, stage_shadow, counts, stats, seeds;
+    // paths: lane 0 doubles as the working set of the stage-level entry points, which run on the main stream
+    Lane lanes[kMaxLanes];
+    uint32_t n_lanes = 1, next_lane = 0;
+    hipEvent_t call_mark = nullptr;
+    DevBuf stats, seeds;
     uint32_t shard_cap = 0;
     uint32_t slot_cap = 0;
     // output
@@ -80,16 +112,8 @@ struct rt_ctx {
     rt_timings last{};
     bool timings_dirty = false;
 
-    PathDev pd() const { return PathDev{ray_o.as<float4>(), ray_d.as<float4>(), hit.as<float4>(), thr.as<float4>(), rad.as<float4>()}; }
-    ShadowQueue sq() const { return ShadowQueue{sq_o.as<float4>(), sq_d.as<float4>(), sq_c.as<float4>(), sq_q.as<uint32_t>()}; }
-    uint32_t* q_count() const { return counts.as<uint32_t>(); }
-    uint32_t* sh_count() const { return counts.as<uint32_t>() + (kMaxBounces + 1); }
-    uint32_t* ext_cursor() const { return counts.as<uint32_t>() + 2 * (kMaxBounces + 1); }   // one work cursor per bounce
-    uint32_t* con_cursor() const { return counts.as<uint32_t>() + 3 * (kMaxBounces + 1); }
-    uint32_t* aux_cursor() const { return counts.as<uint32_t>() + 4 * (kMaxBounces + 1); }   // stage-level entry points
-    // per bounce: kQueueShards append counters for the next-bounce queue, then kQueueShards for the shadow queue
-    uint32_t* shard_counts(uint32_t bounce) const { return counts.as<uint32_t>() + 4 * (kMaxBounces + 1) + 4 + bounce * 2 * kQueueShards; }
-    size_t counts_words() const { return 4 * (kMaxBounces + 1) + 4 + size_t(kMaxBounces) * 2 * kQueueShards; }
+    PathDev pd() const { return lanes[0].pd(); }
+    uint32_t* aux_cursor() const { return lanes[0].aux_cursor(); }
     TraceStats* tstats() const { return stats.as<TraceStats>(); }
 };
 
@@ -126,16 +150,17 @@ hipEvent_t take_event(rt_ctx* c) {
 }
 
 struct StageTimer {  // brackets one launch with events when kernel timing is on
-    rt_ctx* c; Span s{}; bool on;
-    StageTimer(rt_ctx* ctx, int stage) : c(ctx), on((ctx->flags & RT_KERNEL_TIMING) != 0) {
+    rt_ctx* c; hipStream_t st; Span s{}; bool on;
+    StageTimer(rt_ctx* ctx, int stage, hipStream_t stream = nullptr)
+        : c(ctx), st(stream ? stream : ctx->stream), on((ctx->flags & RT_KERNEL_TIMING) != 0) {
         if (!on) return;
         s.stage = stage; s.a = take_event(c); s.b = take_event(c);
         if (!s.a || !s.b) { on = false; return; }
-        (void)hipEventRecord(s.a, c->stream);
+        (void)hipEventRecord(s.a, st);
     }
     ~StageTimer() {
         if (!on) return;
-        (void)hipEventRecord(s.b, c->stream);
+        (void)hipEventRecord(s.b, st);
         c->spans.push_back(s);
     }
 };
@@ -178,7 +203,7 @@ int alloc_paths(rt_ctx* c) {
     uint32_t fpp = c->fpp_cfg;
     if (c->flags & RT_REF_RGBA8_ACCUM) fpp = 1;
     if (fpp == 0) {
-        const uint64_t target = 16ull << 20;  // ~16 M paths in flight keep every CU fed through the late, sparse bounces (~2 GiB of path state)
+        const uint64_t target = 16ull << 20;  // ~16 M paths per lane keep every CU fed through the late, sparse bounces (~2 GiB of path state each)
         fpp = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(64, target / std::max<uint32_t>(1, c->npix))));
     }
     c->fpp = fpp;
@@ -186,15 +211,20 @@ int alloc_paths(rt_ctx* c) {
     if (slots > 0xFFFFFFF0ull) return fail(c, RT_ERR_UNSUPPORTED, "resolution x frames_per_pass exceeds 2^32 path slots");
     c->slot_cap = uint32_t(slots);
     size_t v4 = size_t(slots) * sizeof(float4);
-    HIPCHK(c, c->ray_o.ensure(v4)); HIPCHK(c, c->ray_d.ensure(v4)); HIPCHK(c, c->hit.ensure(v4));
-    HIPCHK(c, c->thr.ensure(v4));   HIPCHK(c, c->rad.ensure(v4));
-    HIPCHK(c, c->q0.ensure(size_t(slots) * 4)); HIPCHK(c, c->q1.ensure(size_t(slots) * 4));
-    HIPCHK(c, c->sq_o.ensure(v4)); HIPCHK(c, c->sq_d.ensure(v4)); HIPCHK(c, c->sq_c.ensure(v4));
-    HIPCHK(c, c->sq_q.ensure(size_t(slots) * 4));
     // staging regions: shard k receives at most ceil(ceil(slots/256)/shards) block-iterations of 256 entries
     c->shard_cap = uint32_t(((slots + kBlock - 1) / kBlock + kQueueShards - 1) / kQueueShards) * kBlock;
-    HIPCHK(c, c->stage_next.ensure(size_t(c->shard_cap) * kQueueShards * 4));
-    HIPCHK(c, c->stage_shadow.ensure(size_t(c->shard_cap) * kQueueShards * 4));
+    for (uint32_t i = 0; i < c->n_lanes; ++i) {
+        Lane& l = c->lanes[i];
+        HIPCHK(c, l.ray_o.ensure(v4)); HIPCHK(c, l.ray_d.ensure(v4)); HIPCHK(c, l.hit.ensure(v4));
+        HIPCHK(c, l.thr.ensure(v4));   HIPCHK(c, l.rad.ensure(v4));
+        HIPCHK(c, l.q0.ensure(size_t(slots) * 4)); HIPCHK(c, l.q1.ensure(size_t(slots) * 4));
+        HIPCHK(c, l.sq_o.ensure(v4)); HIPCHK(c, l.sq_d.ensure(v4)); HIPCHK(c, l.sq_c.ensure(v4));
+        HIPCHK(c, l.sq_q.ensure(size_t(slots) * 4));
+        HIPCHK(c, l.stage_next.ensure(size_t(c->shard_cap) * kQueueShards * 4));
+        HIPCHK(c, l.stage_shadow.ensure(size_t(c->shard_cap) * kQueueShards * 4));
+        HIPCHK(c, l.counts.ensure(sizeof(uint32_t) * Lane::counts_words()));
+        HIPCHK(c, hipMemsetAsync(l.counts.p, 0, l.counts.bytes, c->stream));
+    }
     HIPCHK(c, c->seeds.ensure(size_t(c->npix) * 4));
     HIPCHK(c, c->sum.ensure(size_t(c->npix) * sizeof(float4)));
     HIPCHK(c, c->accum8.ensure(size_t(c->npix) * 4));
@@ -219,56 +249,57 @@ void refresh_camera(rt_ctx* c) {
     c->cam.frame = 0;
 }
 
-// One wavefront pass: `frames` samples of every pixel, bounce by bounce. Leaves radiance in pd.rad.
-int run_pass(rt_ctx* c, uint32_t frames, uint32_t frame_first, uint32_t frame_stride, uint32_t* seeds_out) {
+// One wavefront pass on lane `l`: `frames` samples of every pixel, bounce by bounce. Leaves radiance in l.rad.
+int run_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t frames, uint32_t frame_first, uint32_t frame_stride, uint32_t* seeds_out) {
     const uint32_t n_slots = frames * c->npix;
     const bool count = (c->flags & RT_COUNT_TRAVERSAL) != 0;
-    PathDev pd = c->pd();
-    ShadowQueue sq = c->sq();
-    HIPCHK(c, hipMemsetAsync(c->counts.p, 0, c->counts_words() * 4, c->stream));   // queue lengths, cursors, append counters
+    PathDev pd = l.pd();
+    ShadowQueue sq = l.sq();
+    HIPCHK(c, hipMemsetAsync(l.counts.p, 0, Lane::counts_words() * 4, st));   // queue lengths, cursors, append counters
     {
-        StageTimer tm(c, ST_RAYGEN);
-        hipLaunchKernelGGL(k_raygen, dim3(grid_for(c, n_slots, 8)), dim3(kBlock), 0, c->stream, c->cam, pd, c->npix, n_slots,
+        StageTimer tm(c, ST_RAYGEN, st);
+        hipLaunchKernelGGL(k_raygen, dim3(grid_for(c, n_slots, 8)), dim3(kBlock), 0, st, c->cam, pd, c->npix, n_slots,
                            frame_first, frame_stride, seeds_out);
     }
-    uint32_t* queues[2] = {c->q0.as<uint32_t>(), c->q1.as<uint32_t>()};
+    uint32_t* queues[2] = {l.q0.as<uint32_t>(), l.q1.as<uint32_t>()};
     const uint32_t trace_grid = grid_for(c, n_slots, kTraceBlocksPerCu);
     const uint32_t shade_grid = grid_for(c, n_slots, 4);
     for (uint32_t b = 0; b < c->max_bounces; ++b) {
         const uint32_t* in_q = b == 0 ? nullptr : queues[b & 1];
-        const uint32_t* in_n = b == 0 ? nullptr : c->q_count() + b;
+        const uint32_t* in_n = b == 0 ? nullptr : l.q_count() + b;
         {
-            StageTimer tm(c, ST_EXTEND);
-            if (count) hipLaunchKernelGGL(k_extend<true>, dim3(trace_grid), dim3(kBlock), 0, c->stream, c->sd, pd, in_q, in_n, n_slots, RT_CURSOR(c->ext_cursor() + b), c->tstats());
-            else hipLaunchKernelGGL(k_extend<false>, dim3(trace_grid), dim3(kBlock), 0, c->stream, c->sd, pd, in_q, in_n, n_slots, RT_CURSOR(c->ext_cursor() + b), c->tstats());
+            StageTimer tm(c, ST_EXTEND, st);
+            if (count) hipLaunchKernelGGL(k_extend<true>, dim3(trace_grid), dim3(kBlock), 0, st, c->sd, pd, in_q, in_n, n_slots, RT_CURSOR(l.ext_cursor() + b), c->tstats());
+            else hipLaunchKernelGGL(k_extend<false>, dim3(trace_grid), dim3(kBlock), 0, st, c->sd, pd, in_q, in_n, n_slots, RT_CURSOR(l.ext_cursor() + b), c->tstats());
         }
         {
-            StageTimer tm(c, ST_SHADE);
-            ShadeParams sp{b, c->max_bounces, c->flags, in_q, in_n, n_slots, c->stage_next.as<uint32_t>(), c->shard_counts(b),
-                           c->stage_shadow.as<uint32_t>(), c->shard_counts(b) + kQueueShards, c->shard_cap};
-            if (c->sd.n_mat <= kLdsMats && c->sd.n_emissive <= kLdsLights) hipLaunchKernelGGL(k_shade<true>, dim3(shade_grid), dim3(kBlock), 0, c->stream, c->sd, pd, sq, sp);
-            else hipLaunchKernelGGL(k_shade<false>, dim3(shade_grid), dim3(kBlock), 0, c->stream, c->sd, pd, sq, sp);
+            StageTimer tm(c, ST_SHADE, st);
+            ShadeParams sp{b, c->max_bounces, c->flags, in_q, in_n, n_slots, l.stage_next.as<uint32_t>(), l.shard_counts(b),
+                           l.stage_shadow.as<uint32_t>(), l.shard_counts(b) + kQueueShards, c->shard_cap};
+            if (c->sd.n_mat <= kLdsMats && c->sd.n_emissive <= kLdsLights) hipLaunchKernelGGL(k_shade<true>, dim3(shade_grid), dim3(kBlock), 0, st, c->sd, pd, sq, sp);
+            else hipLaunchKernelGGL(k_shade<false>, dim3(shade_grid), dim3(kBlock), 0, st, c->sd, pd, sq, sp);
         }
         {
-            StageTimer tm(c, ST_SHADE);
+            StageTimer tm(c, ST_SHADE, st);
             const uint32_t per_shard = 4;
-            hipLaunchKernelGGL(k_compact_queues, dim3(kQueueShards * per_shard), dim3(kBlock), 0, c->stream, c->stage_next.as<uint32_t>(),
-                               c->shard_counts(b), queues[(b + 1) & 1], c->q_count() + b + 1, c->stage_shadow.as<uint32_t>(),
-                               c->shard_counts(b) + kQueueShards, c->sq_q.as<uint32_t>(), c->sh_count() + b, c->shard_cap, per_shard);
+            hipLaunchKernelGGL(k_compact_queues, dim3(kQueueShards * per_shard), dim3(kBlock), 0, st, l.stage_next.as<uint32_t>(),
+                               l.shard_counts(b), queues[(b + 1) & 1], l.q_count() + b + 1, l.stage_shadow.as<uint32_t>(),
+                               l.shard_counts(b) + kQueueShards, l.sq_q.as<uint32_t>(), l.sh_count() + b, c->shard_cap, per_shard);
         }
         if (c->sd.n_light + c->sd.n_emissive != 0) {
-            StageTimer tm(c, ST_CONNECT);
+            StageTimer tm(c, ST_CONNECT, st);
             const bool any = c->sd.has_glass == 0;
             auto kern = count ? (any ? k_connect<true, true> : k_connect<true, false>) : (any ? k_connect<false, true> : k_connect<false, false>);
-            hipLaunchKernelGGL(kern, dim3(trace_grid), dim3(kBlock), 0, c->stream, c->sd, pd, sq, c->sh_count() + b, RT_CURSOR(c->con_cursor() + b), c->tstats());
+            hipLaunchKernelGGL(kern, dim3(trace_grid), dim3(kBlock), 0, st, c->sd, pd, sq, l.sh_count() + b, RT_CURSOR(l.con_cursor() + b), c->tstats());
         }
     }
     HIPCHK(c, hipGetLastError());
     return RT_OK;
 }
 
-int finish_pass(rt_ctx* c, uint32_t n_slots) {
-    hipLaunchKernelGGL(k_finish_pass, dim3(1), dim3(64), 0, c->stream, c->q_count(), c->sh_count(), c->ext_cursor(), kMaxBounces + 1, n_slots, c->tstats());
+// Folds the pass's queue lengths into the work counters; runs on the stream that consumed the pass.
+int finish_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t n_slots) {
+    hipLaunchKernelGGL(k_finish_pass, dim3(1), dim3(64), 0, st, l.q_count(), l.sh_count(), l.ext_cursor(), kMaxBounces + 1, n_slots, c->tstats());
     HIPCHK(c, hipGetLastError());
     return RT_OK;
 }
@@ -319,11 +350,19 @@ extern "C" int rt_create(const rt_config* cfg, rt_ctx** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) c->n_cu = std::max(1, prop.multiProcessorCount);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return bail(RT_ERR_DEVICE); }
-    if ((rc = alloc_paths(c)) != RT_OK) return bail(rc);
-    if (c->counts.ensure(sizeof(uint32_t) * c->counts_words()) != hipSuccess || c->stats.ensure(sizeof(TraceStats)) != hipSuccess) {
-        c->err = "counter allocation failed"; return bail(RT_ERR_OOM);
+    c->n_lanes = (c->flags & (RT_SINGLE_STREAM | RT_KERNEL_TIMING | RT_REF_RGBA8_ACCUM)) ? 1 : 2;
+    if (const char* env = std::getenv("RT_HIP_LANES")) {   // tuning aid: 1..4 concurrent passes
+        int v = std::atoi(env);
+        if (v >= 1 && v <= int(kMaxLanes) && !(c->flags & RT_KERNEL_TIMING)) c->n_lanes = uint32_t(v);
     }
-    (void)hipMemsetAsync(c->counts.p, 0, c->counts.bytes, c->stream);
+    for (uint32_t i = 0; i < c->n_lanes; ++i) {
+        Lane& l = c->lanes[i];
+        if (hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&l.pass_done, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&l.consumed, hipEventDisableTiming) != hipSuccess) { c->err = "lane stream/event creation failed"; return bail(RT_ERR_DEVICE); }
+    }
+    if (hipEventCreateWithFlags(&c->call_mark, hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return bail(RT_ERR_DEVICE); }
+    if ((rc = alloc_paths(c)) != RT_OK) return bail(rc);
+    if (c->stats.ensure(sizeof(TraceStats)) != hipSuccess) { c->err = "counter allocation failed"; return bail(RT_ERR_OOM); }
     (void)hipMemsetAsync(c->stats.p, 0, c->stats.bytes, c->stream);
     // sRGB decode table, identical to what a CPU evaluation computes: exact curve in double, rounded once
     float lut[256];
@@ -344,7 +383,13 @@ extern "C" int rt_create(const rt_config* cfg, rt_ctx** out) {
 extern "C" void rt_destroy(rt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)hipDeviceSynchronize();
+    for (Lane& l : c->lanes) {
+        if (l.pass_done) (void)hipEventDestroy(l.pass_done);
+        if (l.consumed) (void)hipEventDestroy(l.consumed);
+        if (l.stream) (void)hipStreamDestroy(l.stream);
+    }
+    if (c->call_mark) (void)hipEventDestroy(c->call_mark);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     if (c->call_begin) (void)hipEventDestroy(c->call_begin);
     if (c->call_end) (void)hipEventDestroy(c->call_end);
@@ -509,18 +554,28 @@ extern "C" int rt_render(rt_ctx* c, uint32_t n_samples) {
     if ((rc = ready_to_render(c)) != RT_OK) return rc;
     if ((rc = bind_device(c)) != RT_OK) return rc;
     begin_call(c);
+    // everything queued on the main stream so far (clears, uploads, stage-level calls) precedes this call's passes
+    HIPCHK(c, hipEventRecord(c->call_mark, c->stream));
+    for (uint32_t i = 0; i < c->n_lanes; ++i) HIPCHK(c, hipStreamWaitEvent(c->lanes[i].stream, c->call_mark, 0));
     uint32_t left = n_samples;
     while (left) {
         uint32_t frames = std::min(left, c->fpp);
         uint32_t frame_first = c->slice_first + c->local_frame * c->slice_stride;
-        if ((rc = run_pass(c, frames, frame_first, c->slice_stride, nullptr)) != RT_OK) return rc;
+        Lane& l = c->lanes[c->next_lane];
+        c->next_lane = (c->next_lane + 1) % c->n_lanes;
+        if (l.busy) HIPCHK(c, hipStreamWaitEvent(l.stream, l.consumed, 0));   // its previous radiance has been accumulated
+        if ((rc = run_pass(c, l, l.stream, frames, frame_first, c->slice_stride, nullptr)) != RT_OK) return rc;
+        HIPCHK(c, hipEventRecord(l.pass_done, l.stream));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, l.pass_done, 0));
         {
             StageTimer tm(c, ST_ACCUM);
-            hipLaunchKernelGGL(k_accumulate, dim3(grid_for(c, c->npix, 8)), dim3(kBlock), 0, c->stream, c->pd(), c->sum.as<float4>(),
+            hipLaunchKernelGGL(k_accumulate, dim3(grid_for(c, c->npix, 8)), dim3(kBlock), 0, c->stream, l.pd(), c->sum.as<float4>(),
                                c->accum8.as<uint32_t>(), c->fb.as<uint32_t>(), c->npix, frames, frame_first, c->slice_stride,
                                (c->flags & RT_REF_RGBA8_ACCUM) ? 1u : 0u);
         }
-        if ((rc = finish_pass(c, frames * c->npix)) != RT_OK) return rc;
+        if ((rc = finish_pass(c, l, c->stream, frames * c->npix)) != RT_OK) return rc;
+        HIPCHK(c, hipEventRecord(l.consumed, c->stream));
+        l.busy = true;
         c->local_frame += frames;
         left -= frames;
     }
@@ -736,8 +791,8 @@ extern "C" int rt_generate_rays(rt_ctx* c, uint32_t frame, float* origins, float
     hipLaunchKernelGGL(k_raygen, dim3(grid_for(c, c->npix, 8)), dim3(kBlock), 0, c->stream, c->cam, c->pd(), c->npix, c->npix, frame, 1u,
                        c->seeds.as<uint32_t>());
     HIPCHK(c, hipGetLastError());
-    if ((rc = download_vec3(c, c->ray_o.as<float4>(), c->npix, origins)) != RT_OK) return rc;
-    if ((rc = download_vec3(c, c->ray_d.as<float4>(), c->npix, directions)) != RT_OK) return rc;
+    if ((rc = download_vec3(c, c->lanes[0].ray_o.as<float4>(), c->npix, origins)) != RT_OK) return rc;
+    if ((rc = download_vec3(c, c->lanes[0].ray_d.as<float4>(), c->npix, directions)) != RT_OK) return rc;
     if (seeds) HIPCHK(c, hipMemcpy(seeds, c->seeds.p, size_t(c->npix) * 4, hipMemcpyDeviceToHost));
     return RT_OK;
 }
@@ -749,10 +804,10 @@ extern "C" int rt_render_radiance(rt_ctx* c, uint32_t frame, float* rgb) {
     if ((rc = ready_to_render(c)) != RT_OK) return rc;
     if ((rc = bind_device(c)) != RT_OK) return rc;
     begin_call(c);
-    if ((rc = run_pass(c, 1, frame, 1, nullptr)) != RT_OK) return rc;
-    if ((rc = finish_pass(c, c->npix)) != RT_OK) return rc;
+    if ((rc = run_pass(c, c->lanes[0], c->stream, 1, frame, 1, nullptr)) != RT_OK) return rc;
+    if ((rc = finish_pass(c, c->lanes[0], c->stream, c->npix)) != RT_OK) return rc;
     end_call(c);
-    return download_vec3(c, c->rad.as<float4>(), c->npix, rgb);
+    return download_vec3(c, c->lanes[0].rad.as<float4>(), c->npix, rgb);
 }
 
 static int bsdf_common(rt_ctx* c, uint32_t n, const rt_material* mats, const float* eta, const float* V, const float* N,

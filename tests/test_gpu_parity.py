@@ -93,6 +93,26 @@ def test_extend_bit_exact_vs_oracle(pair, name, kw):
     assert (g["prim"] != 0xFFFFFFFF).mean() > 0.3
 
 
+def test_extend_bit_exact_on_spatial_split_bvh(rt, oracle, scene_cache):
+    """BinSah::spatial() trees hold duplicated triangles and clipped leaf boxes; ids, distances and the whole path agree
+    with the oracle walking the same tree."""
+    sc = scene_cache("atrium", spatial=True, scale=0.05, width=96, height=54)
+    assert sc.bvh_stats["duplicated_refs"] > 0
+    r = rt.HipRenderer.create(sc, max_bounces=4)
+    o = oracle.OracleScene(sc)
+    rng = np.random.default_rng(13)
+    lo = sc.triangles["v"][..., :3].min(axis=(0, 1)) - 0.5
+    hi = sc.triangles["v"][..., :3].max(axis=(0, 1)) + 0.5
+    ro, rd = random_rays(rng, 20000, lo, hi)
+    g = r.trace_closest(ro, rd)
+    h, _ = o.trace_closest(ro, rd)
+    assert np.array_equal(g["prim"], h["prim"]) and np.array_equal(g["t"], h["t"])
+    assert np.array_equal(g["u"], h["u"]) and np.array_equal(g["v"], h["v"])
+    tmax = rng.uniform(0.5, 20.0, len(ro)).astype(np.float32)
+    assert np.array_equal(r.trace_shadow(ro, rd, tmax), o.trace_shadow(ro, rd, tmax))
+    r.destroy()
+
+
 def test_extend_matches_golden(pair):
     r, _, _ = pair("cornell", {"width": 64, "height": 64})
     g = np.load(GOLD / "cornell64.npz")
@@ -441,6 +461,29 @@ def test_full_size_determinism_and_pass_batching(rt, full_atrium):
     a.reset_accumulator(); a.render(4)
     assert np.array_equal(a.read_sum(), sa)
     a.destroy(); b.destroy()
+
+
+def test_overlapped_passes_match_single_stream_bit_for_bit(rt, full_atrium):
+    """Passes alternate between two streams by default; their accumulation is ordered, so the sum buffer equals the
+    single-stream one exactly, whatever the split of samples over calls. The stage-level entry points share lane 0's
+    buffers and must not disturb, or be disturbed by, passes still in flight."""
+    from ray_tracer_amd import api
+    one = rt.HipRenderer.create(full_atrium, max_bounces=8, frames_per_pass=2, flags=api.RT_SINGLE_STREAM)
+    two = rt.HipRenderer.create(full_atrium, max_bounces=8, frames_per_pass=2)
+    one.render(7)
+    for n in (1, 3, 2, 1):
+        two.dispatch_compute(n)
+    rad = two.render_radiance(3)                      # queued behind the passes above, on lane 0's buffers
+    two.frame_complete()
+    assert two.sample_count() == one.sample_count() == 7
+    assert np.array_equal(one.read_sum(), two.read_sum())
+    assert np.array_equal(rad, one.render_radiance(3))
+    one.dispatch_compute(5); two.dispatch_compute(5)
+    one.frame_complete(); two.frame_complete()
+    assert np.array_equal(one.read_sum(), two.read_sum())
+    c1, c2 = one.counters(), two.counters()
+    assert c1["extend_rays"] == c2["extend_rays"] and c1["shadow_rays"] == c2["shadow_rays"]
+    one.destroy(); two.destroy()
 
 
 def test_full_size_sample_slices_sum_to_the_whole(rt, full_atrium):
