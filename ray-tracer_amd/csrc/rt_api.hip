@@ -50,7 +50,11 @@ struct DevBuf {
 #endif
 // Work distribution of the traversal kernels: a device-wide cursor (dynamic) or block-strided batches of 64 neighbouring items.
 #define RT_CURSOR(p) (RT_DYNAMIC ? (p) : nullptr)
-constexpr uint32_t kTraceBlocksPerCu = 8;   // persistent traversal grid: workgroups per CU (4 waves each)
+// Grid sizes in 256-thread workgroups per CU. Traversal fills every wave slot (8 waves/SIMD at 64 VGPRs); shading is
+// bound by HBM, and two workgroups per CU already saturate it while leaving slots to the other lane's traversal.
+// RT_HIP_TRACE_BLOCKS / RT_HIP_SHADE_BLOCKS override them for tuning runs.
+static uint32_t kTraceBlocksPerCu = 8;
+static uint32_t kShadeBlocksPerCu = 2;
 
 constexpr uint32_t kMaxLanes = 4;
 
@@ -135,6 +139,13 @@ namespace {
 uint32_t grid_for(const rt_ctx* c, uint64_t n, uint32_t blocks_per_cu) {
     uint64_t need = (n + kBlock - 1) / kBlock;
     uint64_t cap = uint64_t(c->n_cu) * blocks_per_cu;
+    return uint32_t(std::max<uint64_t>(1, std::min(need, cap)));
+}
+
+// Persistent traversal grid: `blocks_per_cu` counts 256-thread units, so the waves per CU stay the same whatever kTraceBlock is.
+uint32_t trace_grid_for(const rt_ctx* c, uint64_t n, uint32_t blocks_per_cu) {
+    uint64_t need = (n + kTraceBlock - 1) / kTraceBlock;
+    uint64_t cap = std::max<uint64_t>(1, uint64_t(c->n_cu) * blocks_per_cu * kBlock / kTraceBlock);
     return uint32_t(std::max<uint64_t>(1, std::min(need, cap)));
 }
 
@@ -262,15 +273,15 @@ int run_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t frames, uint32_t frame
                            frame_first, frame_stride, seeds_out);
     }
     uint32_t* queues[2] = {l.q0.as<uint32_t>(), l.q1.as<uint32_t>()};
-    const uint32_t trace_grid = grid_for(c, n_slots, kTraceBlocksPerCu);
-    const uint32_t shade_grid = grid_for(c, n_slots, 4);
+    const uint32_t trace_grid = trace_grid_for(c, n_slots, kTraceBlocksPerCu);
+    const uint32_t shade_grid = grid_for(c, n_slots, kShadeBlocksPerCu);
     for (uint32_t b = 0; b < c->max_bounces; ++b) {
         const uint32_t* in_q = b == 0 ? nullptr : queues[b & 1];
         const uint32_t* in_n = b == 0 ? nullptr : l.q_count() + b;
         {
             StageTimer tm(c, ST_EXTEND, st);
-            if (count) hipLaunchKernelGGL(k_extend<true>, dim3(trace_grid), dim3(kBlock), 0, st, c->sd, pd, in_q, in_n, n_slots, RT_CURSOR(l.ext_cursor() + b), c->tstats());
-            else hipLaunchKernelGGL(k_extend<false>, dim3(trace_grid), dim3(kBlock), 0, st, c->sd, pd, in_q, in_n, n_slots, RT_CURSOR(l.ext_cursor() + b), c->tstats());
+            if (count) hipLaunchKernelGGL(k_extend<true>, dim3(trace_grid), dim3(kTraceBlock), 0, st, c->sd, pd, in_q, in_n, n_slots, RT_CURSOR(l.ext_cursor() + b), c->tstats());
+            else hipLaunchKernelGGL(k_extend<false>, dim3(trace_grid), dim3(kTraceBlock), 0, st, c->sd, pd, in_q, in_n, n_slots, RT_CURSOR(l.ext_cursor() + b), c->tstats());
         }
         {
             StageTimer tm(c, ST_SHADE, st);
@@ -290,7 +301,7 @@ int run_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t frames, uint32_t frame
             StageTimer tm(c, ST_CONNECT, st);
             const bool any = c->sd.has_glass == 0;
             auto kern = count ? (any ? k_connect<true, true> : k_connect<true, false>) : (any ? k_connect<false, true> : k_connect<false, false>);
-            hipLaunchKernelGGL(kern, dim3(trace_grid), dim3(kBlock), 0, st, c->sd, pd, sq, l.sh_count() + b, RT_CURSOR(l.con_cursor() + b), c->tstats());
+            hipLaunchKernelGGL(kern, dim3(trace_grid), dim3(kTraceBlock), 0, st, c->sd, pd, sq, l.sh_count() + b, RT_CURSOR(l.con_cursor() + b), c->tstats());
         }
     }
     HIPCHK(c, hipGetLastError());
@@ -351,6 +362,8 @@ extern "C" int rt_create(const rt_config* cfg, rt_ctx** out) {
     if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) c->n_cu = std::max(1, prop.multiProcessorCount);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return bail(RT_ERR_DEVICE); }
     c->n_lanes = (c->flags & (RT_SINGLE_STREAM | RT_KERNEL_TIMING | RT_REF_RGBA8_ACCUM)) ? 1 : 2;
+    if (const char* env = std::getenv("RT_HIP_TRACE_BLOCKS")) kTraceBlocksPerCu = uint32_t(std::max(1, std::atoi(env)));
+    if (const char* env = std::getenv("RT_HIP_SHADE_BLOCKS")) kShadeBlocksPerCu = uint32_t(std::max(1, std::atoi(env)));
     if (const char* env = std::getenv("RT_HIP_LANES")) {   // tuning aid: 1..4 concurrent passes
         int v = std::atoi(env);
         if (v >= 1 && v <= int(kMaxLanes) && !(c->flags & RT_KERNEL_TIMING)) c->n_lanes = uint32_t(v);
@@ -709,8 +722,8 @@ static int trace_common(rt_ctx* c, uint32_t n, const float* origins, const float
     HIPCHK(c, hipMemsetAsync(c->aux_cursor(), 0, 4, c->stream));
     {
         StageTimer tm(c, shadow ? ST_CONNECT : ST_EXTEND);
-        if (count) hipLaunchKernelGGL(k_trace_rays<true>, dim3(grid_for(c, n, kTraceBlocksPerCu)), dim3(kBlock), 0, c->stream, c->sd, ro.as<float4>(), rd.as<float4>(), n, shadow, hits.as<float4>(), RT_CURSOR(c->aux_cursor()), c->tstats());
-        else hipLaunchKernelGGL(k_trace_rays<false>, dim3(grid_for(c, n, kTraceBlocksPerCu)), dim3(kBlock), 0, c->stream, c->sd, ro.as<float4>(), rd.as<float4>(), n, shadow, hits.as<float4>(), RT_CURSOR(c->aux_cursor()), c->tstats());
+        if (count) hipLaunchKernelGGL(k_trace_rays<true>, dim3(trace_grid_for(c, n, kTraceBlocksPerCu)), dim3(kTraceBlock), 0, c->stream, c->sd, ro.as<float4>(), rd.as<float4>(), n, shadow, hits.as<float4>(), RT_CURSOR(c->aux_cursor()), c->tstats());
+        else hipLaunchKernelGGL(k_trace_rays<false>, dim3(trace_grid_for(c, n, kTraceBlocksPerCu)), dim3(kTraceBlock), 0, c->stream, c->sd, ro.as<float4>(), rd.as<float4>(), n, shadow, hits.as<float4>(), RT_CURSOR(c->aux_cursor()), c->tstats());
     }
     end_call(c);
     HIPCHK(c, hipGetLastError());
@@ -757,7 +770,7 @@ extern "C" int rt_bench_trace(rt_ctx* c, uint32_t n, const float* origins, const
     HIPCHK(c, hipEventCreate(&b));
     auto launch = [&] {
         (void)hipMemsetAsync(c->aux_cursor(), 0, 4, c->stream);
-        hipLaunchKernelGGL(k_trace_rays<false>, dim3(grid_for(c, n, kTraceBlocksPerCu)), dim3(kBlock), 0, c->stream, c->sd, ro.as<float4>(), rd.as<float4>(), n, shadow, hits.as<float4>(), RT_CURSOR(c->aux_cursor()), c->tstats());
+        hipLaunchKernelGGL(k_trace_rays<false>, dim3(trace_grid_for(c, n, kTraceBlocksPerCu)), dim3(kTraceBlock), 0, c->stream, c->sd, ro.as<float4>(), rd.as<float4>(), n, shadow, hits.as<float4>(), RT_CURSOR(c->aux_cursor()), c->tstats());
     };
     launch();  // warm-up
     (void)hipEventRecord(a, c->stream);

@@ -16,6 +16,10 @@
 namespace rtdev {
 
 constexpr uint32_t kBlock = 256;          // 4 wavefronts per workgroup
+#ifndef RT_TRACE_BLOCK
+#define RT_TRACE_BLOCK 256
+#endif
+constexpr uint32_t kTraceBlock = RT_TRACE_BLOCK;   // workgroup size of the traversal kernels
 #ifndef RT_STACK_LDS
 #define RT_STACK_LDS 16
 #endif
@@ -125,14 +129,14 @@ struct LaneRay {
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 
 RT_DEV void stack_push(lds_u32* stack, uint32_t* spill, uint32_t& sp, uint32_t ref) {
-    if (__builtin_expect(sp < kStackLds, 1)) stack[sp * kBlock] = ref;
+    if (__builtin_expect(sp < kStackLds, 1)) stack[sp * kTraceBlock] = ref;
     else spill[sp - kStackLds] = ref;
     ++sp;
 }
 RT_DEV uint32_t stack_pop(const lds_u32* stack, const uint32_t* spill, uint32_t& sp) {
     if (sp == 0) return kDone;
     --sp;
-    if (__builtin_expect(sp < kStackLds, 1)) return stack[sp * kBlock];
+    if (__builtin_expect(sp < kStackLds, 1)) return stack[sp * kTraceBlock];
     return spill[sp - kStackLds];
 }
 
@@ -148,6 +152,29 @@ RT_DEV void node_step(const SceneDev& sc, LaneRay& r, lds_u32* stack, uint32_t* 
     float r_hi = fminf(fminf(fmaxf(r1.x, r2.x), fmaxf(r1.y, r2.y)), fmaxf(r1.z, r2.z));
     float dl = (l_lo <= l_hi && l_hi > 0.0f) ? l_lo : INFINITY;
     float dr = (r_lo <= r_hi && r_hi > 0.0f) ? r_lo : INFINITY;
+#if defined(RT_EXP_VALU)
+    // sensitivity probe: repeat the slab arithmetic on laundered copies; results are identical
+    for (int rep = 0; rep < RT_EXP_VALU; ++rep) {
+        float4 a0 = q0, a1 = q1, a2 = q2;
+        asm volatile("" : "+v"(a0.x), "+v"(a0.y), "+v"(a0.z), "+v"(a0.w), "+v"(a1.x), "+v"(a1.y), "+v"(a1.z), "+v"(a1.w), "+v"(a2.x), "+v"(a2.y), "+v"(a2.z), "+v"(a2.w));
+        f3 xl1 = (f3{a0.x, a0.y, a0.z} - r.o) * r.inv, xl2 = (f3{a0.w, a1.x, a1.y} - r.o) * r.inv;
+        f3 xr1 = (f3{a1.z, a1.w, a2.x} - r.o) * r.inv, xr2 = (f3{a2.y, a2.z, a2.w} - r.o) * r.inv;
+        float xl_lo = fmaxf(fmaxf(fminf(xl1.x, xl2.x), fminf(xl1.y, xl2.y)), fminf(xl1.z, xl2.z));
+        float xl_hi = fminf(fminf(fmaxf(xl1.x, xl2.x), fmaxf(xl1.y, xl2.y)), fmaxf(xl1.z, xl2.z));
+        float xr_lo = fmaxf(fmaxf(fminf(xr1.x, xr2.x), fminf(xr1.y, xr2.y)), fminf(xr1.z, xr2.z));
+        float xr_hi = fminf(fminf(fmaxf(xr1.x, xr2.x), fmaxf(xr1.y, xr2.y)), fmaxf(xr1.z, xr2.z));
+        dl = fminf(dl, (xl_lo <= xl_hi && xl_hi > 0.0f) ? xl_lo : INFINITY);
+        dr = fminf(dr, (xr_lo <= xr_hi && xr_hi > 0.0f) ? xr_lo : INFINITY);
+    }
+#endif
+#if defined(RT_EXP_LOAD)
+    // sensitivity probe: fetch the sibling-ordered neighbour record as well (always in bounds: pairs are stored in twos)
+    for (int rep = 0; rep < RT_EXP_LOAD; ++rep) {
+        const float4* xp = sc.nodes + size_t(r.cur ^ uint32_t(rep + 1)) * 4;
+        float4 x0 = xp[0], x1 = xp[1], x2 = xp[2], x3 = xp[3];
+        asm volatile("" :: "v"(x0.x), "v"(x1.x), "v"(x2.x), "v"(x3.x));
+    }
+#endif
     uint32_t ref_l = __float_as_uint(q3.x), ref_r = __float_as_uint(q3.y);
     // intersects.comp:164-170. dl and dr are never NaN, so the child visited first has the smaller-or-equal entry distance
     // and "far child passes the strict test against the hit distance" implies "near child passes": the shader's four pushes
@@ -199,7 +226,7 @@ RT_DEV void trace_persistent(const SceneDev& sc, const Work& work, uint32_t n, u
     constexpr uint32_t kRefillAt = RT_REFILL_AT;     // refill once this many lanes sit idle
     // consecutive work items a wave owns at a time: RT_CHUNK when there is plenty of work, down to 64 when the queue is
     // short (late bounces), so every resident wave still gets a share
-    const uint32_t waves_total = (gridDim.x * kBlock) >> 6;
+    const uint32_t waves_total = (gridDim.x * kTraceBlock) >> 6;
     uint32_t kChunk = ((n / waves_total) + 63u) & ~63u;
     kChunk = kChunk < 64u ? 64u : (kChunk > RT_CHUNK ? RT_CHUNK : kChunk);
     constexpr uint32_t kLeafBatch = RT_LEAF_BATCH;   // intersect parked leaves once this many lanes wait on one
@@ -214,8 +241,8 @@ RT_DEV void trace_persistent(const SceneDev& sc, const Work& work, uint32_t n, u
     // idle lanes from its current chunk, so the rays it holds stay spatially close, and takes a new chunk from the
     // device-wide cursor only when the current one is used up (or, without a cursor, from a block-strided sequence).
     uint32_t chunk_pos = 0, chunk_end = 0;                                   // wave-uniform
-    uint32_t next_static = ((blockIdx.x * kBlock + threadIdx.x) >> 6) * kChunk;
-    const uint32_t static_stride = (gridDim.x * kBlock >> 6) * kChunk;
+    uint32_t next_static = ((blockIdx.x * kTraceBlock + threadIdx.x) >> 6) * kChunk;
+    const uint32_t static_stride = (gridDim.x * kTraceBlock >> 6) * kChunk;
     for (;;) {
         unsigned long long idle = __ballot(!live);
         uint32_t n_idle = uint32_t(__popcll(idle));
@@ -384,10 +411,10 @@ RT_DEV void flush_counts(uint32_t n_node, uint32_t n_leaf, uint32_t n_tri, unsig
 
 // extend: closest hit for every queued slot (a persistent grid; `cursor` hands out queue entries).
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_extend(SceneDev sc, PathDev pd, const uint32_t* __restrict__ queue,
+__global__ __launch_bounds__(kTraceBlock) void k_extend(SceneDev sc, PathDev pd, const uint32_t* __restrict__ queue,
                                                    const uint32_t* __restrict__ count_ptr, uint32_t count_imm,
                                                    uint32_t* cursor, TraceStats* stats) {
-    __shared__ uint32_t s_stack[kStackLds * kBlock];
+    __shared__ uint32_t s_stack[kStackLds * kTraceBlock];
     const uint32_t n = count_ptr ? *count_ptr : count_imm;
     uint32_t n_node = 0, n_leaf = 0, n_tri = 0;
     ExtendWork work{pd, queue};
@@ -399,9 +426,9 @@ __global__ __launch_bounds__(kBlock) void k_extend(SceneDev sc, PathDev pd, cons
 // When no material of the scene is glass-like (spec_trans > 0.5) "the closest hit is opaque" is the same predicate as
 // "there is a hit", so the query stops at the first hit (ANYHIT); with glass present the closest hit decides.
 template <bool COUNT, bool ANYHIT>
-__global__ __launch_bounds__(kBlock) void k_connect(SceneDev sc, PathDev pd, ShadowQueue sq,
+__global__ __launch_bounds__(kTraceBlock) void k_connect(SceneDev sc, PathDev pd, ShadowQueue sq,
                                                     const uint32_t* __restrict__ count_ptr, uint32_t* cursor, TraceStats* stats) {
-    __shared__ uint32_t s_stack[kStackLds * kBlock];
+    __shared__ uint32_t s_stack[kStackLds * kTraceBlock];
     const uint32_t n = *count_ptr;
     uint32_t n_node = 0, n_leaf = 0, n_tri = 0;
     ConnectWork work{sc, pd, sq};
@@ -804,10 +831,10 @@ struct RayListWork {
 };
 
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_trace_rays(SceneDev sc, const float4* __restrict__ ro, const float4* __restrict__ rd,
+__global__ __launch_bounds__(kTraceBlock) void k_trace_rays(SceneDev sc, const float4* __restrict__ ro, const float4* __restrict__ rd,
                                                        uint32_t n, int shadow, float4* __restrict__ hits, uint32_t* cursor,
                                                        TraceStats* stats) {
-    __shared__ uint32_t s_stack[kStackLds * kBlock];
+    __shared__ uint32_t s_stack[kStackLds * kTraceBlock];
     uint32_t n_node = 0, n_leaf = 0, n_tri = 0;
     RayListWork work{sc, ro, rd, hits, shadow};
     if (shadow && !sc.has_glass) trace_persistent<COUNT, true>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, n_node, n_leaf, n_tri);

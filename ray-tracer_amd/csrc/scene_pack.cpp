@@ -2,6 +2,7 @@
 // Pure CPU code (no HIP calls); compiled into librt_hip.so.
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -71,12 +72,18 @@ int convert_scene(const rt_bvh_node* nodes, uint32_t n_nodes, const rt_triangle*
         return RT_OK;
     }
 
-    // Interior nodes are renumbered in the order a depth-first walk meets them, which keeps a subtree's
-    // records contiguous in memory (the reference's builders already emit nodes depth-first).
+    // Interior nodes are renumbered in the order a depth-first walk meets them, which keeps a subtree's records
+    // close in memory, with one twist: when both children of a node are interior, their two 64-byte records are
+    // given adjacent slots inside one 128-byte cache line. A ray that enters one child and stacks the other (the
+    // common case) then finds the second record already fetched when it pops it.
+    const char* layout_env = std::getenv("RT_HIP_NODE_LAYOUT");
+    const bool pair_layout = !(layout_env && std::strcmp(layout_env, "dfs") == 0);
     std::vector<uint32_t> record_of(n_nodes, 0xFFFFFFFFu);
     std::vector<uint32_t> stack{0};
-    std::vector<uint32_t> interior_order;
+    std::vector<uint32_t> interior_order;          // record slot -> source node (0xFFFFFFFF = padding slot)
     std::vector<uint8_t> seen(n_nodes, 0);
+    record_of[0] = 0;
+    interior_order.push_back(0);
     while (!stack.empty()) {
         uint32_t i = stack.back();
         stack.pop_back();
@@ -86,13 +93,24 @@ int convert_scene(const rt_bvh_node* nodes, uint32_t n_nodes, const rt_triangle*
         const rt_bvh_node& nd = nodes[i];
         if (nd.amt != 0) continue;
         if (uint64_t(nd.idx) + 1 >= n_nodes) { err = "interior node child index out of range"; return RT_ERR_INVALID; }
-        record_of[i] = uint32_t(interior_order.size());
-        interior_order.push_back(i);
+        if (record_of[i] == 0xFFFFFFFFu) {         // not placed by its parent: next free slot
+            record_of[i] = uint32_t(interior_order.size());
+            interior_order.push_back(i);
+        }
+        const bool li = nodes[nd.idx].amt == 0, ri = nodes[nd.idx + 1].amt == 0;
+        if (pair_layout && li && ri && !seen[nd.idx] && !seen[nd.idx + 1] && record_of[nd.idx] == 0xFFFFFFFFu && record_of[nd.idx + 1] == 0xFFFFFFFFu) {
+            if (interior_order.size() & 1u) interior_order.push_back(0xFFFFFFFFu);
+            record_of[nd.idx] = uint32_t(interior_order.size());
+            interior_order.push_back(nd.idx);
+            record_of[nd.idx + 1] = uint32_t(interior_order.size());
+            interior_order.push_back(nd.idx + 1);
+        }
         stack.push_back(nd.idx + 1);
         stack.push_back(nd.idx);
     }
     out.nodes.resize(interior_order.size());
     for (size_t r = 0; r < interior_order.size(); ++r) {
+        if (interior_order[r] == 0xFFFFFFFFu) { out.nodes[r] = NodePair{}; continue; }
         const rt_bvh_node& nd = nodes[interior_order[r]];
         const rt_bvh_node& L = nodes[nd.idx];
         const rt_bvh_node& R = nodes[nd.idx + 1];

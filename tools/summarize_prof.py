@@ -27,7 +27,7 @@ def main(out):
         for r in rows:
             print(f"{short(r['Name']):28s} {r['Calls']:>7s} {float(r['TotalDurationNs'])/1e6:10.3f} {float(r['AverageNs'])/1e3:10.2f} "
                   f"{float(r['MinNs'])/1e3:10.2f} {float(r['MaxNs'])/1e3:10.2f} {float(r['Percentage']):6.2f}")
-    for p in ("pmc_a", "pmc_b", "pmc_c"):
+    for p in ("pmc_a", "pmc_b", "pmc_c", "pmc_d", "pmc_e", "pmc_f"):
         files = glob.glob(os.path.join(out, p, "**", "*counter_collection.csv"), recursive=True)
         for f in files:
             print("\n== counters:", os.path.relpath(f, out), "(sum over dispatches, per kernel)")
