@@ -2,7 +2,7 @@
 
 The directory is named `ray-tracer_amd`; import it as `ray_tracer_amd` (the repository root carries a small alias module).
 """
-from . import api, scene, scenes  # noqa: F401
+from . import api, loaders, scene, scenes  # noqa: F401
 from .api import load_library  # noqa: F401
 from .renderer import HipRenderer  # noqa: F401
 from .scene import Scene  # noqa: F401
