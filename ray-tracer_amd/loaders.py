@@ -262,3 +262,233 @@ def save_frame(renderer, path) -> Path:
         path = Path(os.getcwd()) / path
     Image.fromarray(renderer.read_framebuffer(), "RGBA").save(path)
     return path
+
+
+# ---------------------------------------------------------------------------------------------------------
+# glTF 2.0 (.gltf + external/embedded buffers, or .glb), as `Scene::from_gltf` reads it (src/scene/gltf.rs:130-433)
+# ---------------------------------------------------------------------------------------------------------
+
+_GLTF_DTYPES = {5120: np.int8, 5121: np.uint8, 5122: np.int16, 5123: np.uint16, 5125: np.uint32, 5126: np.float32}
+_GLTF_WIDTH = {"SCALAR": 1, "VEC2": 2, "VEC3": 3, "VEC4": 4, "MAT2": 4, "MAT3": 9, "MAT4": 16}
+
+
+def gltf_default_camera() -> np.ndarray:
+    """`camera_sponza()`, the camera from_gltf installs before looking for one in the file (gltf.rs:59-80,139)."""
+    return look_at_camera(1920, 1080, (3.0, 2.0, 0.0), (-4.0, 2.0, 0.0), 1.0, 55.0, 0.0)
+
+
+class _Gltf:
+    def __init__(self, path: Path):
+        import base64
+        import json
+        import struct
+        self.base = path.parent
+        raw = path.read_bytes()
+        self.glb_bin = None
+        if raw[:4] == b"glTF":
+            _, _, total = struct.unpack_from("<III", raw, 0)
+            off, doc = 12, None
+            while off + 8 <= min(total, len(raw)):
+                n, kind = struct.unpack_from("<II", raw, off)
+                chunk = raw[off + 8: off + 8 + n]
+                if kind == 0x4E4F534A:
+                    doc = json.loads(chunk.decode("utf-8"))
+                elif kind == 0x004E4942 and self.glb_bin is None:
+                    self.glb_bin = chunk
+                off += 8 + n + (-n % 4)
+            if doc is None:
+                raise SceneFormatError("GLB without a JSON chunk")
+            self.doc = doc
+        else:
+            self.doc = json.loads(raw.decode("utf-8"))
+        self._b64 = base64
+        self._buffers = {}
+
+    def _uri_bytes(self, uri: str) -> bytes:
+        from urllib.parse import unquote
+        if uri.startswith("data:"):
+            return self._b64.b64decode(uri.split(",", 1)[1])
+        return (self.base / unquote(uri)).read_bytes()
+
+    def buffer(self, index: int) -> bytes:
+        if index not in self._buffers:
+            b = self.doc["buffers"][index]
+            if "uri" in b:
+                self._buffers[index] = self._uri_bytes(b["uri"])
+            elif self.glb_bin is not None:
+                self._buffers[index] = self.glb_bin
+            else:
+                raise SceneFormatError("buffer without uri outside a GLB container")
+        return self._buffers[index]
+
+    def view_bytes(self, index: int) -> bytes:
+        v = self.doc["bufferViews"][index]
+        off = v.get("byteOffset", 0)
+        return self.buffer(v["buffer"])[off: off + v["byteLength"]]
+
+    def accessor(self, index: int) -> np.ndarray:
+        a = self.doc["accessors"][index]
+        if "sparse" in a:
+            raise SceneFormatError("sparse accessors are not supported")
+        dt = np.dtype(_GLTF_DTYPES[a["componentType"]]).newbyteorder("<")
+        width, count = _GLTF_WIDTH[a["type"]], a["count"]
+        if "bufferView" not in a:
+            return np.zeros((count, width), dtype=dt)
+        v = self.doc["bufferViews"][a["bufferView"]]
+        start = v.get("byteOffset", 0) + a.get("byteOffset", 0)
+        elem = dt.itemsize * width
+        stride = v.get("byteStride", 0) or elem
+        buf = self.buffer(v["buffer"])
+        if start + stride * (count - 1) + elem > len(buf) and count:
+            raise SceneFormatError("accessor reaches beyond its buffer")
+        out = np.ndarray((count, width), dtype=dt, buffer=buf, offset=start, strides=(stride, dt.itemsize))
+        return np.array(out)
+
+    def accessor_f32(self, index: int) -> np.ndarray:
+        """Values as f32; normalised integer encodings are expanded the way glTF prescribes (`into_f32`)."""
+        a = self.doc["accessors"][index]
+        raw = self.accessor(index)
+        ct = a["componentType"]
+        if ct == 5126:
+            return raw.astype(np.float32)
+        scale = {5121: 255.0, 5123: 65535.0, 5120: 127.0, 5122: 32767.0}.get(ct)
+        if scale is None:
+            return raw.astype(np.float32)
+        out = raw.astype(np.float32) / np.float32(scale)
+        return np.maximum(out, np.float32(-1.0)) if ct in (5120, 5122) else out
+
+    def image(self, index: int) -> np.ndarray:
+        import io
+        from PIL import Image
+        im = self.doc["images"][index]
+        data = self._uri_bytes(im["uri"]) if "uri" in im else self.view_bytes(im["bufferView"])
+        with Image.open(io.BytesIO(data)) as pil:
+            return np.asarray(pil.convert("RGBA"), dtype=np.uint8).copy()
+
+    def node_matrix(self, node) -> np.ndarray:
+        """Column-major 4x4 as a (4,4) array M with M @ [x,y,z,1] the transformed point (`node.transform().matrix()`)."""
+        if "matrix" in node:
+            return np.asarray(node["matrix"], dtype=np.float32).reshape(4, 4).T.copy()
+        t = np.asarray(node.get("translation", [0, 0, 0]), dtype=np.float32)
+        x, y, z, w = (np.float32(v) for v in node.get("rotation", [0, 0, 0, 1]))
+        s = np.asarray(node.get("scale", [1, 1, 1]), dtype=np.float32)
+        one, two = np.float32(1), np.float32(2)
+        r = np.array([[one - two * (y * y + z * z), two * (x * y - z * w), two * (x * z + y * w)],
+                      [two * (x * y + z * w), one - two * (x * x + z * z), two * (y * z - x * w)],
+                      [two * (x * z - y * w), two * (y * z + x * w), one - two * (x * x + y * y)]], dtype=np.float32)
+        m = np.eye(4, dtype=np.float32)
+        m[:3, :3] = r * s[None, :]
+        m[:3, 3] = t
+        return m
+
+
+def _gltf_texture_source(g: _Gltf, info) -> int:
+    """Texture reference -> *image* index, the id the reference stores (gltf.rs:299-317)."""
+    if not info:
+        return api.NO_TEXTURE
+    tex = g.doc["textures"][info["index"]]
+    return int(tex["source"]) if "source" in tex else api.NO_TEXTURE
+
+
+def gltf_material(g: _Gltf, index) -> np.ndarray:
+    """`process_material` (gltf.rs:292-413). `index` None selects glTF's default material."""
+    md = g.doc["materials"][index] if index is not None else {}
+    pbr = md.get("pbrMetallicRoughness", {})
+    ext = md.get("extensions", {})
+    m = default_material(1)
+    m["base_colour"][0, :3] = np.asarray(pbr.get("baseColorFactor", [1, 1, 1, 1]), dtype=np.float32)[:3]
+    m["metallic"] = np.float32(pbr.get("metallicFactor", 1.0))
+    m["roughness"] = np.float32(pbr.get("roughnessFactor", 1.0))
+    m["ior"] = np.float32(ext.get("KHR_materials_ior", {}).get("ior", 1.5)) if "KHR_materials_ior" in ext else np.float32(1.5)
+    m["spec_trans"] = np.float32(ext.get("KHR_materials_transmission", {}).get("transmissionFactor", 0.0))
+    emissive = np.asarray(md.get("emissiveFactor", [0, 0, 0]), dtype=np.float32)
+    strength = np.float32(ext["KHR_materials_emissive_strength"].get("emissiveStrength", 1.0)) if "KHR_materials_emissive_strength" in ext else np.float32(0.0)
+    m["emission"][0, :3] = emissive * strength if strength != 0 else emissive
+    # the reference looks for the clearcoat block among the extensions of pbrMetallicRoughness (gltf.rs:350-363)
+    cc = pbr.get("extensions", {}).get("KHR_materials_clearcoat")
+    cc = cc if isinstance(cc, dict) else {}
+    m["clearcoat"] = np.float32(cc.get("clearcoatFactor", 0.0))
+    m["clearcoat_roughness"] = np.float32(cc.get("clearcoatRoughnessFactor", 0.0))
+    m["shade_smooth"] = 0
+    m["base_color_tex"] = _gltf_texture_source(g, pbr.get("baseColorTexture"))
+    m["metallic_roughness_tex"] = _gltf_texture_source(g, pbr.get("metallicRoughnessTexture"))
+    m["normal_tex"] = _gltf_texture_source(g, md.get("normalTexture"))
+    m["emission_tex"] = _gltf_texture_source(g, md.get("emissiveTexture"))
+    return m
+
+
+def load_gltf(path) -> Scene:
+    """Components of a glTF file: every image as an RGBA8 texture, one material per primitive, triangles of the default
+    scene's node hierarchy in world space, camera from a top-level camera node if there is one (gltf.rs:131-290,415-432).
+    Like the reference, only indexed primitives produce triangles and normals are transformed by the node matrix itself."""
+    path = Path(path)
+    g = _Gltf(path)
+    doc = g.doc
+    textures = [g.image(i) for i in range(len(doc.get("images", [])))]
+    scenes = doc.get("scenes", [])
+    if not scenes:
+        raise SceneFormatError("No scenes found in GLTF file")
+    root = scenes[doc["scene"]] if "scene" in doc else scenes[0]
+    camera = gltf_default_camera()
+
+    for ni in root.get("nodes", []):
+        node = doc["nodes"][ni]
+        if "camera" in node:
+            cam = doc["cameras"][node["camera"]]
+            if cam.get("type") != "perspective":
+                raise NotImplementedError("ORTHOGRAPHIC CAMERA NOT IMPLEMENTED")
+            m = g.node_matrix(node)
+            camera["focal_length"] = np.float32(1.0) / np.tan(np.float32(cam["perspective"]["yfov"]) * np.float32(0.5), dtype=np.float32)
+            camera["location"][0, :3] = m[:3, 3]
+            camera["rotation"][0] = m.T.reshape(-1)      # stored column-major, not transposed: as upstream (gltf.rs:425)
+
+    mats, tris = [], []
+
+    def visit(ni, parent):
+        node = doc["nodes"][ni]
+        m = (parent @ g.node_matrix(node)).astype(np.float32)
+        if "mesh" in node:
+            for prim in doc["meshes"][node["mesh"]].get("primitives", []):
+                mat_index = len(mats)
+                mats.append(gltf_material(g, prim.get("material")))
+                attrs = prim.get("attributes", {})
+                if "POSITION" not in attrs:
+                    continue
+                pos = g.accessor_f32(attrs["POSITION"])
+                nrm = g.accessor_f32(attrs["NORMAL"]) if "NORMAL" in attrs else np.tile(np.float32([0, 0, 1]), (len(pos), 1))
+                uv = g.accessor_f32(attrs["TEXCOORD_0"]) if "TEXCOORD_0" in attrs else np.zeros((len(pos), 2), np.float32)
+                if "indices" not in prim:
+                    continue
+                idx = g.accessor(prim["indices"]).astype(np.int64).reshape(-1)
+                idx = idx[: len(idx) // 3 * 3].reshape(-1, 3)
+                if len(idx) and idx.max() >= len(pos):
+                    raise SceneFormatError("primitive index out of range")
+                a, t = m[:3, :3], m[:3, 3]
+                # transform_point3: x_axis*p.x + y_axis*p.y + z_axis*p.z + w_axis, in f32
+                wp = (pos[:, 0:1] * a[:, 0][None] + pos[:, 1:2] * a[:, 1][None] + pos[:, 2:3] * a[:, 2][None] + t[None]).astype(np.float32)
+                wn = (nrm[:, 0:1] * a[:, 0][None] + nrm[:, 1:2] * a[:, 1][None] + nrm[:, 2:3] * a[:, 2][None]).astype(np.float32)
+                len2 = (wn[:, 0] * wn[:, 0] + wn[:, 1] * wn[:, 1]).astype(np.float32) + wn[:, 2] * wn[:, 2]
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    wn = (wn * (np.float32(1.0) / np.sqrt(len2, dtype=np.float32))[:, None]).astype(np.float32)
+                tris.append(_triangles(wp[idx], wn[idx], uv[idx, :2], mat_index))
+        for ci in node.get("children", []):
+            visit(ci, m)
+
+    for ni in root.get("nodes", []):
+        visit(ni, np.eye(4, dtype=np.float32))
+
+    triangles = np.concatenate(tris) if tris else np.zeros(0, dtype=api.TRIANGLE)
+    materials = np.concatenate(mats) if mats else np.zeros(0, dtype=api.MATERIAL)
+    return Scene(triangles=triangles, materials=materials, camera=camera, textures=textures, name=path.stem)
+
+
+def from_gltf(path, spatial: bool = True, threads: int = 0, build_lights: bool = False, log=print) -> Scene:
+    """`Scene::from_gltf` (gltf.rs:131-156). Upstream builds the BVH only, so emissive meshes are never sampled directly;
+    `build_lights=True` adds the light table the YAML path builds."""
+    sc = load_gltf(path)
+    if log:
+        log(f"Triangles: {len(sc.triangles)}")
+    sc.build_bvh(threads=threads, spatial=spatial)
+    if build_lights:
+        sc.build_lights()
+    return sc

@@ -1,0 +1,125 @@
+"""glTF ingestion (src/scene/gltf.rs:130-433) on a hand-built asset: node hierarchy (TRS + matrix), strided/normalised
+accessors, embedded and external buffers, GLB container, material extensions, image-index texture ids, camera node."""
+import base64
+import json
+import struct
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from ray_tracer_amd import api, loaders
+
+
+def build_asset(tmp_path, glb=False):
+    from PIL import Image
+    Image.new("RGB", (2, 2), (255, 0, 0)).save(tmp_path / "red.png")
+    Image.new("RGBA", (3, 1), (0, 255, 0, 128)).save(tmp_path / "green.png")
+    # one quad: interleaved POSITION(f32x3) + NORMAL(f32x3), stride 24; then uv as normalised u8 pairs (stride 4); then u16 indices
+    pos_n = np.array([[0, 0, 0, 0, 0, 1], [1, 0, 0, 0, 0, 1], [1, 1, 0, 0, 0, 1], [0, 1, 0, 0, 0, 1]], np.float32).tobytes()
+    uv = np.array([[0, 0, 9, 9], [255, 0, 9, 9], [255, 255, 9, 9], [0, 255, 9, 9]], np.uint8).tobytes()
+    idx = np.array([0, 1, 2, 0, 2, 3, 1], np.uint16).tobytes() + b"\0\0"            # 7 indices: the stray one is dropped
+    blob = pos_n + uv + idx
+    doc = {
+        "asset": {"version": "2.0"}, "scene": 0,
+        "scenes": [{"nodes": [0, 2]}],
+        "nodes": [
+            {"translation": [10, 0, 0], "scale": [2, 2, 2], "children": [1]},
+            {"mesh": 0, "rotation": [0, 0, 0.70710678, 0.70710678]},                 # 90 degrees about +Z
+            {"camera": 0, "matrix": [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 5, 6, 7, 1]},
+        ],
+        "cameras": [{"type": "perspective", "perspective": {"yfov": 1.0, "znear": 0.1}}],
+        "meshes": [{"primitives": [{"attributes": {"POSITION": 0, "NORMAL": 1, "TEXCOORD_0": 2}, "indices": 3, "material": 0},
+                                   {"attributes": {"POSITION": 0}, "material": 1}]}],   # no indices: contributes a material only
+        "materials": [
+            {"pbrMetallicRoughness": {"baseColorFactor": [0.25, 0.5, 0.75, 1], "metallicFactor": 0.1, "roughnessFactor": 0.6,
+                                      "baseColorTexture": {"index": 0},
+                                      "extensions": {"KHR_materials_clearcoat": {"clearcoatFactor": 0.8, "clearcoatRoughnessFactor": 0.2}}},
+             "emissiveFactor": [1, 0.5, 0.25], "emissiveTexture": {"index": 1},
+             "extensions": {"KHR_materials_emissive_strength": {"emissiveStrength": 4.0}, "KHR_materials_ior": {"ior": 1.33},
+                            "KHR_materials_transmission": {"transmissionFactor": 0.9}}},
+            {},
+        ],
+        "textures": [{"source": 1}, {"source": 0}],
+        "images": [{"uri": "red.png"}, {"uri": "green.png"}],
+        "accessors": [
+            {"bufferView": 0, "componentType": 5126, "count": 4, "type": "VEC3"},
+            {"bufferView": 0, "byteOffset": 12, "componentType": 5126, "count": 4, "type": "VEC3"},
+            {"bufferView": 1, "componentType": 5121, "normalized": True, "count": 4, "type": "VEC2"},
+            {"bufferView": 2, "componentType": 5123, "count": 7, "type": "SCALAR"},
+        ],
+        "bufferViews": [
+            {"buffer": 0, "byteOffset": 0, "byteLength": 96, "byteStride": 24},
+            {"buffer": 0, "byteOffset": 96, "byteLength": 16, "byteStride": 4},
+            {"buffer": 0, "byteOffset": 112, "byteLength": 14},
+        ],
+        "buffers": [{"byteLength": len(blob)}],
+    }
+    if glb:
+        js = json.dumps(doc).encode()
+        js += b" " * (-len(js) % 4)
+        body = struct.pack("<II", len(js), 0x4E4F534A) + js + struct.pack("<II", len(blob), 0x004E4942) + blob
+        path = tmp_path / "asset.glb"
+        path.write_bytes(struct.pack("<4sII", b"glTF", 2, 12 + len(body)) + body)
+    else:
+        doc["buffers"][0]["uri"] = "data:application/octet-stream;base64," + base64.b64encode(blob).decode()
+        path = tmp_path / "asset.gltf"
+        path.write_text(json.dumps(doc))
+    return path
+
+
+@pytest.mark.parametrize("glb", [False, True])
+def test_gltf_components(tmp_path, glb):
+    sc = loaders.load_gltf(build_asset(tmp_path, glb))
+    assert len(sc.triangles) == 2 and len(sc.materials) == 2 and len(sc.textures) == 2
+    # world = T(10,0,0) * S(2) * Rz(90): (x, y, 0) -> (10 - 2y, 2x, 0)
+    want = np.array([[[10, 0, 0], [10, 2, 0], [8, 2, 0]], [[10, 0, 0], [8, 2, 0], [8, 0, 0]]], np.float32)
+    np.testing.assert_allclose(sc.triangles["v"][:, :, :3], want, atol=1e-5)
+    np.testing.assert_allclose(sc.triangles["n"][:, :, :3], np.broadcast_to([0, 0, 1], (2, 3, 3)), atol=1e-6)   # normalised after scaling
+    assert np.array_equal(sc.triangles["uv"][0], [[0, 0], [1, 0], [1, 1]]) and np.array_equal(sc.triangles["uv"][1], [[0, 0], [1, 1], [0, 1]])
+    assert list(sc.triangles["material_idx"]) == [0, 0]
+    m = sc.materials[0]
+    assert np.allclose(m["base_colour"][:3], [0.25, 0.5, 0.75]) and m["metallic"] == np.float32(0.1) and m["roughness"] == np.float32(0.6)
+    assert np.allclose(m["emission"][:3], [4, 2, 1]) and m["ior"] == np.float32(1.33) and m["spec_trans"] == np.float32(0.9)
+    assert m["clearcoat"] == np.float32(0.8) and m["clearcoat_roughness"] == np.float32(0.2) and m["shade_smooth"] == 0
+    assert m["base_color_tex"] == 1 and m["emission_tex"] == 0 and m["normal_tex"] == api.NO_TEXTURE      # image indices, not texture indices
+    d = sc.materials[1]                                                                                    # glTF default material
+    assert np.allclose(d["base_colour"][:3], 1) and d["metallic"] == 1 and d["roughness"] == 1 and d["ior"] == np.float32(1.5)
+    assert (d["emission"][:3] == 0).all() and d["clearcoat_roughness"] == 0 and d["base_color_tex"] == api.NO_TEXTURE
+    assert sc.textures[0].shape == (2, 2, 4) and tuple(sc.textures[0][0, 0]) == (255, 0, 0, 255)
+    assert sc.textures[1].shape == (1, 3, 4) and tuple(sc.textures[1][0, 0]) == (0, 255, 0, 128)
+    cam = sc.camera
+    assert np.allclose(cam["location"][0, :3], [5, 6, 7]) and np.isclose(cam["focal_length"][0], 1 / np.tan(0.5))
+    assert tuple(cam["resolution"][0]) == (1920, 1080) and cam["focus_distance"][0] == 55
+    assert np.array_equal(cam["rotation"][0], np.float32([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 5, 6, 7, 1]))
+
+
+def test_from_gltf_builds_the_tree_but_no_light_table(tmp_path):
+    sc = loaders.from_gltf(build_asset(tmp_path), log=None)
+    assert len(sc.bvh) >= 1 and len(sc.emissive_tris) == 0            # upstream never calls build_lights here
+    lit = loaders.from_gltf(build_asset(tmp_path), build_lights=True, log=None)
+    assert len(lit.emissive_tris) == 2
+
+
+def test_gltf_without_scene_or_with_sparse_accessor_is_rejected(tmp_path):
+    (tmp_path / "a.gltf").write_text(json.dumps({"asset": {"version": "2.0"}}))
+    with pytest.raises(loaders.SceneFormatError, match="No scenes"):
+        loaders.load_gltf(tmp_path / "a.gltf")
+
+
+REF = Path("/root/reference/scenes")
+
+
+@pytest.mark.skipif(not (REF / "glTF/DragonAttenuation.gltf").exists(), reason="reference assets are not present on this machine")
+@pytest.mark.parametrize("rel", ["glTF/DragonAttenuation.gltf", "Interior/room.gltf", "sponza/Sponza.gltf"])
+def test_material_tables_of_the_shipped_gltf_documents_parse(rel):
+    """The shipped .gltf documents come without their .bin geometry; their material tables still exercise the mapping."""
+    g = loaders._Gltf(REF / rel)
+    n = len(g.doc.get("materials", []))
+    assert n > 0
+    n_img = len(g.doc.get("images", []))
+    for i in range(n):
+        m = loaders.gltf_material(g, i)[0]
+        assert np.isfinite([m["metallic"], m["roughness"], m["ior"], m["spec_trans"]]).all()
+        for k in ("base_color_tex", "metallic_roughness_tex", "normal_tex", "emission_tex"):
+            assert m[k] == api.NO_TEXTURE or m[k] < n_img
