@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--frames-per-pass", type=int, default=0)
+    ap.add_argument("--bvh", choices=("spatial", "object"), default="spatial",
+                    help="split policy of the host BVH build; spatial = BinSah::spatial(), what Scene::build_bvh uses upstream")
     return ap.parse_args()
 
 
@@ -79,22 +81,30 @@ def main():
     if args.scene != "cornell":
         kw["scale"] = args.scale
     t0 = time.time()
-    scene = gen(**kw).finalize()
+    scene = gen(**kw).finalize(spatial=args.bvh == "spatial")
     t_scene = time.time() - t0
 
     # BVH build-time baseline (stand-in for the reference's criterion bench, benches/bvh.rs:11-40: clone the triangles,
     # build, 10 samples): median wall time of the library's binned-SAH builder on this scene, rank 0 only.
     bvh_bench = None
     if rank == 0 and not args.no_cpu_baseline:
-        ts = []
-        for _ in range(10):
+        ts, ts_spatial = [], []
+        n_in = 0
+        for i in range(10):
             clone = gen(**kw)
+            n_in = len(clone.triangles)
             t1 = time.perf_counter()
             clone.build_bvh()
             ts.append((time.perf_counter() - t1) * 1e3)
-        bvh_bench = {"builder": "binned SAH, object splits (BinSah::default parameters)", "triangles": int(len(scene.triangles)),
+            if i < 5:
+                clone = gen(**kw)
+                t1 = time.perf_counter()
+                clone.build_bvh(spatial=True)
+                ts_spatial.append((time.perf_counter() - t1) * 1e3)
+        bvh_bench = {"builder": "binned SAH, object splits (BinSah::default parameters)", "triangles": int(n_in),
                      "median_ms": float(np.median(ts)), "min_ms": float(min(ts)), "samples": 10, "threads": min(64, os.cpu_count() or 1),
-                     "mtris_per_s": len(scene.triangles) / float(np.median(ts)) / 1e3}
+                     "mtris_per_s": n_in / float(np.median(ts)) / 1e3,
+                     "spatial_splits_median_ms": float(np.median(ts_spatial)), "spatial_splits_samples": 5}
 
     r = rt.HipRenderer.create(scene, max_bounces=args.bounces, device=local_rank, frames_per_pass=args.frames_per_pass)
     from ray_tracer_amd.distributed import frame_slice
@@ -157,6 +167,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{scene.name} {args.width}x{args.height}, {args.bounces} bounces, NEE+MIS, 1 spp per step per GPU",
                    "triangles": int(len(scene.triangles)), "bvh_nodes": int(len(scene.bvh)), "emissive_tris": int(len(scene.emissive_tris)),
+                   "bvh": f"binned SAH, {args.bvh} splits", "duplicated_triangles": int(scene.bvh_stats.get("duplicated_refs", 0)),
                    "parallelism": f"sample-slice x{world}" if world > 1 else "single GPU", "frames_per_pass": int(args.frames_per_pass)},
         "samples_per_sec": world * args.steps / elapsed,
         "samples_per_sec_vs_rtx3080_readme_5_to_10": [world * args.steps / elapsed / 10.0, world * args.steps / elapsed / 5.0],
@@ -176,7 +187,7 @@ def main():
         rc.destroy()
         rtm = rt.HipRenderer.create(scene, max_bounces=args.bounces, device=local_rank, flags=api.RT_KERNEL_TIMING,
                                     frames_per_pass=args.frames_per_pass)
-        rtm.render(2)
+        rtm.render(k)                # warm-up with a pass of the same size, so every traced launch is comparable
         rtm.reset_accumulator()
         rtm.render(k)
         tm = rtm.last_timer_perf()
@@ -188,16 +199,18 @@ def main():
         # HBM-side bytes per launch of the same kernel, from the committed rocprofv3 counter passes of this exact workload
         # (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; tools/profile_gpu.sh). Counters cannot be read from inside this process.
         traffic = None
-        tfile = ROOT / "profiles" / "r1_v2_traffic.json"
+        tfile = ROOT / "profiles" / "r1_v3_traffic.json"
         default_cfg = (args.scene == "atrium" and args.scale == 1.0 and (args.width, args.height, args.bounces) == (1920, 1080, 8)
-                       and args.frames_per_pass == 0)
+                       and args.frames_per_pass == 0 and args.bvh == "spatial")
         if default_cfg and tfile.exists():
             traffic = json.loads(tfile.read_text()).get("k_extend", {}).get("hbm_bytes_per_launch")
         result["roofline"] = {
             "kernel": "k_extend", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "traffic_note": "bytes per launch beyond L2 (Infinity Cache hits included), profiles/r1_v2_traffic.json; algorithmic bytes "
+            "traffic_note": "bytes per launch beyond L2 (Infinity Cache hits included), profiles/r1_v3_traffic.json; algorithmic bytes "
                             "charge every node visit to HBM, so achieved may exceed the HBM peak when caches serve the BVH",
+            "measured_in": "a separate context with per-kernel events (single stream: kernels run alone, as in the rocprofv3 "
+                           "single-stream trace under profiles/); the timed region overlaps two passes, which lengthens individual launches",
             "bytes_per_launch": b_ext / max(1, tm["extend_launches"]), "avg_launch_ms": tm["extend_ms"] / max(1, tm["extend_launches"]),
             "launches": tm["extend_launches"], "samples": k,
             "bytes_per_ray": b_ext / max(1, c["extend_rays"]),

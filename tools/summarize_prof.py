@@ -20,8 +20,8 @@ TRAFFIC = {}
 
 
 def main(out):
-    for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
-        print("== kernel trace stats:", os.path.relpath(f, out))
+    for f in sorted(glob.glob(os.path.join(out, "trace*", "**", "*kernel_stats.csv"), recursive=True)):
+        print("== kernel trace stats:", os.path.relpath(f, out), "(trace/ = single stream, trace_overlapped/ = default two-lane run)")
         rows = list(csv.DictReader(open(f)))
         print(f"{'kernel':28s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>6s}")
         for r in rows:
