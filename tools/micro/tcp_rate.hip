@@ -58,6 +58,19 @@ __global__ __launch_bounds__(256) void k(const float4* __restrict__ recs, uint32
             const float2* p = reinterpret_cast<const float2*>(recs + size_t(idx) * 4);
             float2 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4], f = p[5], g = p[6], h = p[7];
             acc += a.x + b.y + c.x + d.y + e.x + f.y + g.x + h.y;
+        } else if (MODE == 12) {         // 4 x global_load_lds_dwordx4 (record gathered into LDS), then one ds_read_b128 back per quarter
+            __shared__ float4 stage[4][4][64];
+            const uint32_t w = threadIdx.x >> 6;
+            const float4* p = recs + size_t(idx) * 4;
+            typedef __attribute__((address_space(1))) const void* gptr_t;
+            typedef __attribute__((address_space(3))) void* lptr_t;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                __builtin_amdgcn_global_load_lds((gptr_t)(p + q), (lptr_t)&stage[w][q][0], 16, 0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            float4 a = stage[w][0][lane], b = stage[w][1][lane], c = stage[w][2][lane], d = stage[w][3][lane];
+            acc += a.x + b.y + c.z + d.w;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         } else if (MODE == 9) {          // 4 x dwordx4, chunk order rotated by lane
             const float4* p = recs + size_t(idx) * 4;
             float4 a = p[(0 + lane) & 3], b = p[(1 + lane) & 3], c = p[(2 + lane) & 3], d = p[(3 + lane) & 3];
@@ -104,13 +117,13 @@ int main() {
     (void)hipMemset(recs, 0, max_recs * 64);
     (void)hipMalloc(&out, size_t(grid) * 256 * 4);
     const char* names[] = {"4 x dwordx4 per lane", "quad-cooperative 4 x dwordx4", "1 x dwordx4 per lane", "2 x dwordx4 per lane", "2 x dwordx4 offsets 0,32",
-                           "4 x dwordx4 even lanes only", "4 x dwordx4 lanes 0-31 only", "8 x dwordx2 per lane", "4 x dwordx4, 128-B aligned", "4 x dwordx4 rotated by lane", "4 x dwordx4 rotated by lane>>1", "2 x dwordx4 rotated by lane"};
-    const int n_instr[] = {4, 4, 1, 2, 2, 4, 4, 8, 4, 4, 4, 2};
+                           "4 x dwordx4 even lanes only", "4 x dwordx4 lanes 0-31 only", "8 x dwordx2 per lane", "4 x dwordx4, 128-B aligned", "4 x dwordx4 rotated by lane", "4 x dwordx4 rotated by lane>>1", "2 x dwordx4 rotated by lane", "4 x global_load_lds_dwordx4 + ds_read"};
+    const int n_instr[] = {4, 4, 1, 2, 2, 4, 4, 8, 4, 4, 4, 2, 4};
     for (uint32_t log2n : {8u, 14u}) {          // 64 KiB, 1 MiB, 16 MiB, 256 MiB working sets
         uint32_t mask = (1u << log2n) - 1u;
-        float ms[12] = {run<0>(recs, mask, grid, iters, out), run<1>(recs, mask, grid, iters, out), run<2>(recs, mask, grid, iters, out), run<3>(recs, mask, grid, iters, out),
-                       run<4>(recs, mask, grid, iters, out), run<5>(recs, mask, grid, iters, out), run<6>(recs, mask, grid, iters, out), run<7>(recs, mask, grid, iters, out), run<8>(recs, mask, grid, iters, out), run<9>(recs, mask, grid, iters, out), run<10>(recs, mask, grid, iters, out), run<11>(recs, mask, grid, iters, out)};
-        for (int m = 0; m < 12; ++m) {
+        float ms[13] = {run<0>(recs, mask, grid, iters, out), run<1>(recs, mask, grid, iters, out), run<2>(recs, mask, grid, iters, out), run<3>(recs, mask, grid, iters, out),
+                       run<4>(recs, mask, grid, iters, out), run<5>(recs, mask, grid, iters, out), run<6>(recs, mask, grid, iters, out), run<7>(recs, mask, grid, iters, out), run<8>(recs, mask, grid, iters, out), run<9>(recs, mask, grid, iters, out), run<10>(recs, mask, grid, iters, out), run<11>(recs, mask, grid, iters, out), run<12>(recs, mask, grid, iters, out)};
+        for (int m = 0; m < 13; ++m) {
             double wave_instr_per_cu = double(iters) * n_instr[m] * 32;          // 32 waves per CU
             double cyc = ms[m] * 1e-3 * 2.4e9 / wave_instr_per_cu;
             double recs_per_s = double(grid) * 256 * iters / (ms[m] * 1e-3);
