@@ -199,11 +199,13 @@ def main():
         # HBM-side bytes per launch of the same kernel, from the committed rocprofv3 counter passes of this exact workload
         # (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; tools/profile_gpu.sh). Counters cannot be read from inside this process.
         traffic = None
+        prof = {}
         tfile = ROOT / "profiles" / "r1_v3_traffic.json"
         default_cfg = (args.scene == "atrium" and args.scale == 1.0 and (args.width, args.height, args.bounces) == (1920, 1080, 8)
                        and args.frames_per_pass == 0 and args.bvh == "spatial")
         if default_cfg and tfile.exists():
-            traffic = json.loads(tfile.read_text()).get("k_extend", {}).get("hbm_bytes_per_launch")
+            prof = json.loads(tfile.read_text()).get("k_extend", {})
+            traffic = prof.get("hbm_bytes_per_launch")
         result["roofline"] = {
             "kernel": "k_extend", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -211,6 +213,8 @@ def main():
                             "charge every node visit to HBM, so achieved may exceed the HBM peak when caches serve the BVH",
             "measured_in": "a separate context with per-kernel events (single stream: kernels run alone, as in the rocprofv3 "
                            "single-stream trace under profiles/); the timed region overlaps two passes, which lengthens individual launches",
+            "l2_hit_rate": prof.get("l2_hit_rate"), "active_lanes_per_valu_instruction": prof.get("active_lanes_per_valu_instruction"),
+            "occupancy": "8 waves/SIMD (62 VGPRs, 16 KiB LDS per 256-thread workgroup, 8 workgroups per CU: every wave slot)",
             "bytes_per_launch": b_ext / max(1, tm["extend_launches"]), "avg_launch_ms": tm["extend_ms"] / max(1, tm["extend_launches"]),
             "launches": tm["extend_launches"], "samples": k,
             "bytes_per_ray": b_ext / max(1, c["extend_rays"]),

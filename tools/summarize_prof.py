@@ -46,9 +46,14 @@ def main(out):
                 a = agg[k]
                 if "TCC_HIT_sum" in a and a["TCC_HIT_sum"] + a["TCC_MISS_sum"] > 0:
                     print(f"    -> L2 hit rate {a['TCC_HIT_sum']/(a['TCC_HIT_sum']+a['TCC_MISS_sum']):.4f}")
+                    TRAFFIC.setdefault(k, {})["l2_hit_rate"] = a["TCC_HIT_sum"] / (a["TCC_HIT_sum"] + a["TCC_MISS_sum"])
                 if "SQ_WAVE_CYCLES" in a and a["SQ_WAVE_CYCLES"] > 0:
                     print(f"    -> wait_any/wave_cycles {a.get('SQ_WAIT_ANY',0)/a['SQ_WAVE_CYCLES']:.3f}  valu_active/wave_cycles {a.get('SQ_ACTIVE_INST_VALU',0)/a['SQ_WAVE_CYCLES']:.3f}"
                           f"  mean waves in flight (wave_cycles/busy_cycles) {a['SQ_WAVE_CYCLES']/max(1,a.get('SQ_BUSY_CYCLES',1)):.2f}")
+                if "SQ_THREAD_CYCLES_VALU" in a and a.get("SQ_ACTIVE_INST_VALU", 0) > 0:
+                    TRAFFIC.setdefault(k, {})["active_lanes_per_valu_instruction"] = a["SQ_THREAD_CYCLES_VALU"] / a["SQ_ACTIVE_INST_VALU"]
+                if "SQ_WAVES" in a:
+                    TRAFFIC.setdefault(k, {})["lds_bytes_per_workgroup"] = meta[k][3]
                 if "FETCH_SIZE" in a:
                     TRAFFIC.setdefault(k, {})["fetch_kb_per_launch_raw"] = a["FETCH_SIZE"] / max(1, len(calls[k]))
                     TRAFFIC[k]["launches_fetch_pass"] = len(calls[k])
