@@ -219,7 +219,8 @@ int alloc_paths(rt_ctx* c) {
     }
     c->fpp = fpp;
     uint64_t slots = uint64_t(fpp) * c->npix;
-    if (slots > 0xFFFFFFF0ull) return fail(c, RT_ERR_UNSUPPORTED, "resolution x frames_per_pass exceeds 2^32 path slots");
+    // work distribution adds whole chunk strides to 32-bit item indices: keep them clear of wrap-around
+    if (slots > 0x7FFFFFFFull) return fail(c, RT_ERR_UNSUPPORTED, "resolution x frames_per_pass exceeds 2^31 path slots");
     c->slot_cap = uint32_t(slots);
     size_t v4 = size_t(slots) * sizeof(float4);
     // staging regions: shard k receives at most ceil(ceil(slots/256)/shards) block-iterations of 256 entries

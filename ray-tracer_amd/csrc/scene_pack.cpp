@@ -80,6 +80,7 @@ int convert_scene(const rt_bvh_node* nodes, uint32_t n_nodes, const rt_triangle*
     const bool pair_layout = !(layout_env && std::strcmp(layout_env, "dfs") == 0);
     std::vector<uint32_t> record_of(n_nodes, 0xFFFFFFFFu);
     std::vector<uint32_t> stack{0};
+    std::vector<uint32_t> depth_stack{0};          // depth of the node at the same position of `stack`
     std::vector<uint32_t> interior_order;          // record slot -> source node (0xFFFFFFFF = padding slot)
     std::vector<uint8_t> seen(n_nodes, 0);
     record_of[0] = 0;
@@ -87,6 +88,10 @@ int convert_scene(const rt_bvh_node* nodes, uint32_t n_nodes, const rt_triangle*
     while (!stack.empty()) {
         uint32_t i = stack.back();
         stack.pop_back();
+        const uint32_t depth = depth_stack.back();
+        depth_stack.pop_back();
+        // the traversal stack holds at most one entry per level: 65 entries serve trees of depth <= 64 (main.comp:6)
+        if (depth > 64) { err = "BVH deeper than 64 levels"; return RT_ERR_UNSUPPORTED; }
         if (i >= n_nodes) { err = "node index out of range"; return RT_ERR_INVALID; }
         if (seen[i]) { err = "BVH is not a tree (node reached twice)"; return RT_ERR_INVALID; }
         seen[i] = 1;
@@ -107,6 +112,8 @@ int convert_scene(const rt_bvh_node* nodes, uint32_t n_nodes, const rt_triangle*
         }
         stack.push_back(nd.idx + 1);
         stack.push_back(nd.idx);
+        depth_stack.push_back(depth + 1);
+        depth_stack.push_back(depth + 1);
     }
     out.nodes.resize(interior_order.size());
     for (size_t r = 0; r < interior_order.size(); ++r) {

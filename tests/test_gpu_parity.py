@@ -163,6 +163,21 @@ def test_extend_deep_tree_uses_stack_beyond_lds(rt, oracle):
     r.destroy()
 
 
+def test_trees_deeper_than_the_stack_bound_are_rejected(rt, oracle):
+    """65 stack entries serve 64 levels (main.comp:6); the deepest legal tree traces correctly, one level more is refused
+    at upload instead of overrunning the stack."""
+    ok = chain_scene(64)
+    r = rt.HipRenderer.create(ok, max_bounces=2)
+    ro = np.array([[0.1, 0.0, -2.0], [0.3, 0.2, -2.0]], np.float32)
+    rd = np.tile(np.array([[0, 0, 1]], np.float32), (2, 1))
+    g = r.trace_closest(ro, rd)
+    h, _ = oracle.OracleScene(ok).trace_closest(ro, rd)
+    assert np.array_equal(g["prim"], h["prim"]) and np.array_equal(g["t"], h["t"])
+    r.destroy()
+    with pytest.raises(RuntimeError, match="deeper than 64"):
+        rt.HipRenderer.create(chain_scene(65), max_bounces=2)
+
+
 def test_extend_empty_scene_and_ragged_sizes(rt):
     from ray_tracer_amd.scene import Scene, default_material, look_at_camera
     cam = look_at_camera(37, 23, (0, 0, 3), (0, 0, 0))
