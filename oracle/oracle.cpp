@@ -211,6 +211,9 @@ inline float dist_aabb(const Ray& ray, const rt_bvh_node& n) {  // intersects.co
     return (tmin <= tmax && tmax > 0.0f) ? tmin : INF;
 }
 
+// Optional per-node visit histogram (analysis aid for the BVH-layout tools; off unless a buffer is installed).
+static std::atomic<uint32_t*> g_visit_hist{nullptr};
+
 // hit_meshes, intersects.comp:124-175
 Hit hit_meshes(const Scene& sc, const Ray& ray, bool shadow, Counters* cn) {
     Hit hit;
@@ -219,8 +222,11 @@ Hit hit_meshes(const Scene& sc, const Ray& ray, bool shadow, Counters* cn) {
     uint32_t sp = 0;
     stack[sp++] = 0;
     uint64_t pops = 0, leafs = 0, tests = 0;
+    uint32_t* const hist = g_visit_hist.load(std::memory_order_relaxed);
     while (sp > 0) {
-        const rt_bvh_node& node = sc.nodes[stack[--sp]];
+        const uint32_t node_index = stack[--sp];
+        const rt_bvh_node& node = sc.nodes[node_index];
+        if (hist) __atomic_fetch_add(&hist[node_index], 1u, __ATOMIC_RELAXED);
         if (node.amt != 0) {
             ++leafs;
             for (uint32_t k = 0; k < node.amt; ++k) {
@@ -806,6 +812,10 @@ void* orc_scene_create(const void* blob, const uint64_t sizes[6], uint32_t n_bvh
     return sc;
 }
 void orc_scene_destroy(void* s) { delete static_cast<Scene*>(s); }
+
+// Installs (or, with nullptr, removes) a caller-owned array of one counter per reference-layout BVH node; every node
+// popped by hit_meshes increments its counter.
+void orc_set_visit_histogram(uint32_t* per_node) { g_visit_hist.store(per_node); }
 
 void orc_scene_set_textures(void* s, const rt_texture* tex, uint32_t n, const rt_texture* sky) {
     Scene* sc = static_cast<Scene*>(s);

@@ -50,10 +50,11 @@ struct DevBuf {
 #endif
 // Work distribution of the traversal kernels: a device-wide cursor (dynamic) or block-strided batches of 64 neighbouring items.
 #define RT_CURSOR(p) (RT_DYNAMIC ? (p) : nullptr)
-// Grid sizes in 256-thread workgroups per CU. Traversal fills every wave slot (8 waves/SIMD at 64 VGPRs); shading is
-// bound by HBM, and two workgroups per CU already saturate it while leaving slots to the other lane's traversal.
+// Grid sizes in 256-thread units per CU. Traversal runs RT_TRACE_WAVES_PER_EU waves per SIMD (the LDS each workgroup
+// needs for stack heads and resident node records sets how many fit); shading is bound by HBM, and two workgroups per
+// CU already saturate it while leaving slots to the other lane's traversal.
 // RT_HIP_TRACE_BLOCKS / RT_HIP_SHADE_BLOCKS override them for tuning runs.
-static uint32_t kTraceBlocksPerCu = 8;
+static uint32_t kTraceBlocksPerCu = RT_TRACE_WAVES_PER_EU;
 static uint32_t kShadeBlocksPerCu = 2;
 
 constexpr uint32_t kMaxLanes = 4;
@@ -471,7 +472,7 @@ extern "C" int rt_upload_scene(rt_ctx* c, const void* blob, const uint64_t sizes
     sd.cdf = c->cdf.as<float>();
     sd.has_glass = 0;
     for (uint32_t i = 0; i < n_mat; ++i) sd.has_glass |= mats[i].spec_trans > 0.5f ? 1u : 0u;
-    sd.root_ref = gs.root_ref; sd.n_tri = n_tri; sd.n_light = n_light; sd.n_emissive = n_emissive; sd.n_mat = n_mat;
+    sd.root_ref = gs.root_ref; sd.n_hot = gs.n_hot; sd.n_tri = n_tri; sd.n_light = n_light; sd.n_emissive = n_emissive; sd.n_mat = n_mat;
     // The shader sizes the CDF from its 16-byte padded binding; an empty table is bound as one dummy word
     // (src/vulkan/path_tracer/descriptors.rs:85-93).
     uint32_t seen = n_emissive;

@@ -48,9 +48,14 @@ struct alignas(16) TriShade {
 };
 static_assert(sizeof(TriIsect) == 48 && sizeof(TriShade) == 64, "triangle streams");
 
+// Node records placed at the front of the record array in order of decreasing surface area (the traversal kernels copy
+// as many of them into LDS as their LDS budget allows).
+constexpr uint32_t kHotNodeSlots = 2048;
+
 struct GpuScene {
     std::vector<NodePair> nodes;
     uint32_t root_ref = kRefNone;
+    uint32_t n_hot = 0;          // records [0, n_hot) are the largest-area interior nodes, largest first
     std::vector<TriIsect> isect;
     std::vector<TriShade> shade;
 };

@@ -17,11 +17,11 @@ namespace rtdev {
 
 constexpr uint32_t kBlock = 256;          // 4 wavefronts per workgroup
 #ifndef RT_TRACE_BLOCK
-#define RT_TRACE_BLOCK 256
+#define RT_TRACE_BLOCK 1024
 #endif
 constexpr uint32_t kTraceBlock = RT_TRACE_BLOCK;   // workgroup size of the traversal kernels
 #ifndef RT_STACK_LDS
-#define RT_STACK_LDS 16
+#define RT_STACK_LDS 8
 #endif
 #ifndef RT_REFILL_AT
 #define RT_REFILL_AT 24
@@ -35,7 +35,14 @@ constexpr uint32_t kTraceBlock = RT_TRACE_BLOCK;   // workgroup size of the trav
 #ifndef RT_LEAF_BATCH
 #define RT_LEAF_BATCH 16
 #endif
-constexpr uint32_t kStackLds = RT_STACK_LDS;  // traversal stack entries kept in LDS per lane (1 KiB per entry per workgroup)
+#ifndef RT_HOT_LDS
+#define RT_HOT_LDS 768
+#endif
+#ifndef RT_TRACE_WAVES_PER_EU
+#define RT_TRACE_WAVES_PER_EU 8
+#endif
+constexpr uint32_t kStackLds = RT_STACK_LDS;  // traversal stack entries kept in LDS per lane (4 x kTraceBlock bytes per entry per workgroup)
+constexpr uint32_t kHotLds = RT_HOT_LDS;      // node records (64 B each) every traversal workgroup keeps in LDS
 constexpr uint32_t kStackMax = 65;        // MAX_BVH_DEPTH + 1, main.comp:6 / intersects.comp:130
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kRefNone = 0x7FFFFFFFu;
@@ -51,6 +58,7 @@ struct SceneDev {
     const float4* __restrict__ light_tris; // per emissive triangle: {v0, area} {v1, Le.r} {v2, Le.g} {unit normal, Le.b}
     const float* __restrict__ cdf;        // un-normalised running power
     uint32_t root_ref, n_tri, n_light, n_emissive, n_mat;
+    uint32_t n_hot;                       // records [0, n_hot) of `nodes` are the largest-area nodes, largest first
     uint32_t has_glass;                   // any material with spec_trans > 0.5 (decides how shadow rays may terminate)
     uint32_t cdf_len_seen;                // length the light selector searches (true length unless the padded-length quirk is on)
     TexView tex;
@@ -109,17 +117,18 @@ RT_DEV uint32_t wave_sum(uint32_t v) {
 //     the parked leaves are intersected together. Box tests and triangle tests are therefore each executed with
 //     most lanes active instead of being serialised inside every iteration.
 //
-// The traversal stack keeps its first kStackLds entries per lane in LDS (entry-major, so lanes never conflict on a
-// bank) and the rest, up to the reference's bound of 65, in per-lane scratch.
+// The traversal stack keeps its top entry in a register, the next kStackLds - 1 per lane in LDS (entry-major, so lanes
+// never conflict on a bank) and the rest, up to the reference's bound of 65, in per-lane scratch.
 
-constexpr uint32_t kDone = 0x7FFFFFFEu;       // lane has no node to visit
+constexpr uint32_t kDone = 0x7FFFFFFEu;       // lane has no node to visit; also the "empty" marker of the stack
 
 struct LaneRay {
     f3 o, d, inv;
     float t, u, v;
     uint32_t prim;
-    uint32_t cur;        // node record index, leaf reference, or kDone
-    uint32_t sp;
+    uint32_t cur;        // node record index, leaf reference, or kDone (lanes without a ray always hold kDone)
+    uint32_t tos;        // top of the stack (kDone = stack empty)
+    uint32_t sp;         // entries below the top; entry k (1-based) lives in memory slot k, slot 0 always reads kDone
     uint32_t item;       // index of the work item this lane is tracing
 };
 
@@ -128,22 +137,97 @@ struct LaneRay {
 // completion every iteration then has to wait for.
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 
-RT_DEV void stack_push(lds_u32* stack, uint32_t* spill, uint32_t& sp, uint32_t ref) {
-    if (__builtin_expect(sp < kStackLds, 1)) stack[sp * kTraceBlock] = ref;
-    else spill[sp - kStackLds] = ref;
-    ++sp;
+// Memory slots of the stack: slot 0 is a permanent kDone (so popping an empty stack needs no test), slots
+// 1 .. kStackLds-1 are in LDS, higher ones in scratch.
+RT_DEV void slot_store(lds_u32* stack, uint32_t* spill, uint32_t slot, uint32_t v) {
+    if (__builtin_expect(slot < kStackLds, 1)) stack[slot * kTraceBlock] = v;
+    else spill[slot - kStackLds] = v;
 }
-RT_DEV uint32_t stack_pop(const lds_u32* stack, const uint32_t* spill, uint32_t& sp) {
-    if (sp == 0) return kDone;
-    --sp;
-    if (__builtin_expect(sp < kStackLds, 1)) return stack[sp * kTraceBlock];
-    return spill[sp - kStackLds];
+RT_DEV uint32_t slot_load(const lds_u32* stack, const uint32_t* spill, uint32_t slot) {
+    if (__builtin_expect(slot < kStackLds, 1)) return stack[slot * kTraceBlock];
+    return spill[slot - kStackLds];
+}
+// push: the old top moves to memory (an empty top rewrites slot 0 with the kDone it already holds)
+RT_DEV void stack_push(lds_u32* stack, uint32_t* spill, LaneRay& r, uint32_t ref, bool lds_only) {
+    r.sp += r.tos != kDone ? 1u : 0u;
+    if (lds_only) stack[r.sp * kTraceBlock] = r.tos;
+    else slot_store(stack, spill, r.sp, r.tos);
+    r.tos = ref;
+}
+// pop: returns the top; the entry below becomes the top
+RT_DEV uint32_t stack_pop(const lds_u32* stack, const uint32_t* spill, LaneRay& r, bool lds_only) {
+    uint32_t top = r.tos;
+    r.tos = lds_only ? uint32_t(stack[r.sp * kTraceBlock]) : slot_load(stack, spill, r.sp);
+    r.sp -= r.sp != 0u ? 1u : 0u;
+    return top;
+}
+
+// The busiest node records live in LDS, one copy per workgroup, stored chunk-major (all first 16-byte chunks, then all
+// second ones, ...): the 16 lanes a ds_read_b128 serves per cycle then spread over 16 bank groups by record index
+// instead of piling onto the 4 a record-major layout would give them.
+struct HotNodes {
+    const lds_v4f* tab;     // kHotLds x 4 chunks
+    uint32_t n;             // records [0, n) are resident
+};
+typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) v2u lds_v2u;
+
+RT_DEV void load_hot_nodes(const SceneDev& sc, v4f* s_hot, uint32_t n) {
+    for (uint32_t i = threadIdx.x; i < n * 4u; i += kTraceBlock) {
+        float4 v = sc.nodes[i];
+        s_hot[(i & 3u) * kHotLds + (i >> 2)] = v4f{v.x, v.y, v.z, v.w};
+    }
+    __syncthreads();
+}
+
+// Fetches the 56 used bytes of node record `cur`: resident records from LDS, the others from global memory. Both kinds
+// are requested before either is waited for. Written as one asm block because the two sources fill the same registers
+// for disjoint sets of lanes: the compiler cannot know the sets are disjoint and would wait for the global data before
+// issuing the LDS reads (adding the two latencies); inside the block the lane mask is split by hand and restored.
+// `lds_a` / `lds_b` are the LDS byte addresses of chunk 0 and chunk 2 of the record (meaningful for resident records).
+RT_DEV void fetch_node(const float4* __restrict__ nodes, uint32_t cur, uint32_t n_resident, uint32_t lds_a, uint32_t lds_b,
+                       v4f& q0, v4f& q1, v4f& q2, v2u& refs) {
+    const uint32_t goff = cur << 6;               // byte offset of the record: the node array stays below 4 GiB (2^26 records)
+    uint64_t saved;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "v_cmp_gt_u32 vcc, %[nres], %[cur]\n\t"
+        "s_and_b64 exec, %[sv], vcc\n\t"
+        "ds_read_b128 %[q0], %[la]\n\t"
+        "ds_read_b128 %[q1], %[la] offset:%[c1]\n\t"
+        "ds_read_b128 %[q2], %[lb]\n\t"
+        "ds_read_b64 %[rf], %[lb] offset:%[c1]\n\t"
+        "s_andn2_b64 exec, %[sv], vcc\n\t"
+        "global_load_dwordx4 %[q0], %[go], %[base]\n\t"
+        "global_load_dwordx4 %[q1], %[go], %[base] offset:16\n\t"
+        "global_load_dwordx4 %[q2], %[go], %[base] offset:32\n\t"
+        "global_load_dwordx2 %[rf], %[go], %[base] offset:48\n\t"
+        "s_mov_b64 exec, %[sv]\n\t"
+        "s_waitcnt vmcnt(0) lgkmcnt(0)"
+        : [q0] "=&v"(q0), [q1] "=&v"(q1), [q2] "=&v"(q2), [rf] "=&v"(refs), [sv] "=&s"(saved)
+        : [nres] "s"(n_resident), [cur] "v"(cur), [la] "v"(lds_a), [lb] "v"(lds_b), [go] "v"(goff), [base] "s"(nodes),
+          [c1] "n"(kHotLds * 16)
+        : "vcc", "memory");
 }
 
 // One interior-node visit: slab test of both children (intersects.comp:103-121), ordered descent.
-RT_DEV void node_step(const SceneDev& sc, LaneRay& r, lds_u32* stack, uint32_t* spill) {
-    const float4* np = sc.nodes + size_t(r.cur) * 4;
-    float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+RT_DEV void node_step(const SceneDev& sc, LaneRay& r, lds_u32* stack, uint32_t* spill, const HotNodes& hot) {
+    float4 q0, q1, q2;
+    uint32_t ref_l, ref_r;
+    if (kHotLds != 0) {
+        static_assert(kHotLds * 16 < 65536, "chunk stride must fit the 16-bit offset of an LDS instruction");
+        v4f a, b, c;
+        v2u refs;
+        const uint32_t lds_a = uint32_t(uintptr_t(hot.tab + r.cur));
+        fetch_node(sc.nodes, r.cur, hot.n, lds_a, lds_a + 2u * kHotLds * 16u, a, b, c, refs);
+        q0 = make_float4(a.x, a.y, a.z, a.w); q1 = make_float4(b.x, b.y, b.z, b.w); q2 = make_float4(c.x, c.y, c.z, c.w);
+        ref_l = refs.x; ref_r = refs.y;
+    } else {
+        const float4* np = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sc.nodes) + (r.cur << 6));
+        q0 = np[0]; q1 = np[1]; q2 = np[2];
+        uint2 refs = *reinterpret_cast<const uint2*>(np + 3);
+        ref_l = refs.x; ref_r = refs.y;
+    }
     f3 l1 = (f3{q0.x, q0.y, q0.z} - r.o) * r.inv, l2 = (f3{q0.w, q1.x, q1.y} - r.o) * r.inv;
     f3 r1 = (f3{q1.z, q1.w, q2.x} - r.o) * r.inv, r2 = (f3{q2.y, q2.z, q2.w} - r.o) * r.inv;
     float l_lo = fmaxf(fmaxf(fminf(l1.x, l2.x), fminf(l1.y, l2.y)), fminf(l1.z, l2.z));
@@ -167,33 +251,31 @@ RT_DEV void node_step(const SceneDev& sc, LaneRay& r, lds_u32* stack, uint32_t* 
         dr = fminf(dr, (xr_lo <= xr_hi && xr_hi > 0.0f) ? xr_lo : INFINITY);
     }
 #endif
-#if defined(RT_EXP_LOAD)
-    // sensitivity probe: fetch the sibling-ordered neighbour record as well (always in bounds: pairs are stored in twos)
-    for (int rep = 0; rep < RT_EXP_LOAD; ++rep) {
-        const float4* xp = sc.nodes + size_t(r.cur ^ uint32_t(rep + 1)) * 4;
-        float4 x0 = xp[0], x1 = xp[1], x2 = xp[2], x3 = xp[3];
-        asm volatile("" :: "v"(x0.x), "v"(x1.x), "v"(x2.x), "v"(x3.x));
-    }
-#endif
-    uint32_t ref_l = __float_as_uint(q3.x), ref_r = __float_as_uint(q3.y);
     // intersects.comp:164-170. dl and dr are never NaN, so the child visited first has the smaller-or-equal entry distance
     // and "far child passes the strict test against the hit distance" implies "near child passes": the shader's four pushes
     // reduce to {enter near, stack far} / {enter near} / {nothing to enter: pop}.
     bool left_first = dl < dr;
     float d_near = left_first ? dl : dr, d_far = left_first ? dr : dl;
     uint32_t near_ref = left_first ? ref_l : ref_r, far_ref = left_first ? ref_r : ref_l;
-    if (d_near < r.t) {
-        if (d_far < r.t) stack_push(stack, spill, r.sp, far_ref);
-        r.cur = near_ref;
+    const bool go_near = d_near < r.t, push = d_far < r.t;
+    // wave-uniform choice: unless some lane's stack has outgrown its LDS slots (rare), pushes and pops are single LDS operations
+    const bool lds_only = __builtin_amdgcn_ballot_w64(r.sp + 1u >= kStackLds) == 0ull;
+    if (__builtin_expect(lds_only, 1)) {
+        if (push) stack_push(stack, spill, r, far_ref, true);
+        if (go_near) r.cur = near_ref;
+        else r.cur = stack_pop(stack, spill, r, true);
     } else {
-        r.cur = stack_pop(stack, spill, r.sp);
+        if (push) stack_push(stack, spill, r, far_ref, false);
+        if (go_near) r.cur = near_ref;
+        else r.cur = stack_pop(stack, spill, r, false);
     }
 }
 
 // Moeller-Trumbore exactly as hit_triangle evaluates it (intersects.comp:37-64) on the 48-byte record
 // {v0, n.x} {v1-v0, n.y} {v2-v0, n.z}.
 RT_DEV void triangle_test(const SceneDev& sc, LaneRay& r, uint32_t tri) {
-    const float4* tp = sc.isect + size_t(tri) * 3;
+    // 32-bit byte offset (the 48-byte records of at most 2^25 triangles stay below 4 GiB): scalar base + lane offset addressing
+    const float4* tp = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sc.isect) + tri * 48u);
     float4 A = tp[0], B = tp[1], C = tp[2];        // all 48 bytes requested at once: one round trip per triangle
     f3 pn = {A.w, B.w, C.w};
     float ndd = dot(pn, r.d);
@@ -221,7 +303,7 @@ RT_DEV void triangle_test(const SceneDev& sc, LaneRay& r, uint32_t tri) {
 // ANYHIT turns the closest-hit search into an occlusion query (stop at the first hit below tmax).
 //   void store(uint32_t i, const LaneRay& r)
 template <bool COUNT, bool ANYHIT, class Work>
-RT_DEV void trace_persistent(const SceneDev& sc, const Work& work, uint32_t n, uint32_t* cursor, lds_u32* stack,
+RT_DEV void trace_persistent(const SceneDev& sc, const Work& work, uint32_t n, uint32_t* cursor, lds_u32* stack, const HotNodes& hot,
                              uint32_t& n_node, uint32_t& n_leaf, uint32_t& n_tri) {
     constexpr uint32_t kRefillAt = RT_REFILL_AT;     // refill once this many lanes sit idle
     // consecutive work items a wave owns at a time: RT_CHUNK when there is plenty of work, down to 64 when the queue is
@@ -232,7 +314,8 @@ RT_DEV void trace_persistent(const SceneDev& sc, const Work& work, uint32_t n, u
     constexpr uint32_t kLeafBatch = RT_LEAF_BATCH;   // intersect parked leaves once this many lanes wait on one
     uint32_t spill[kStackMax - kStackLds];
     LaneRay r;
-    r.cur = kDone; r.sp = 0; r.item = 0; r.prim = kNoPrim; r.t = INFINITY; r.u = r.v = 0.0f;
+    r.cur = kDone; r.tos = kDone; r.sp = 0; r.item = 0; r.prim = kNoPrim; r.t = INFINITY; r.u = r.v = 0.0f;
+    stack[0] = kDone;                                // slot 0 of this lane's stack: what a pop of the empty stack reads
     r.o = r.d = r.inv = f3{0.0f, 0.0f, 0.0f};
     bool live = false;
     bool drained = false;       // wave-uniform: the cursor has passed the end of the work list
@@ -244,7 +327,7 @@ RT_DEV void trace_persistent(const SceneDev& sc, const Work& work, uint32_t n, u
     uint32_t next_static = ((blockIdx.x * kTraceBlock + threadIdx.x) >> 6) * kChunk;
     const uint32_t static_stride = (gridDim.x * kTraceBlock >> 6) * kChunk;
     for (;;) {
-        unsigned long long idle = __ballot(!live);
+        unsigned long long idle = __builtin_amdgcn_ballot_w64(!live);
         uint32_t n_idle = uint32_t(__popcll(idle));
         if (!drained && n_idle >= kRefillAt) {
             if (chunk_pos >= chunk_end) {
@@ -268,39 +351,56 @@ RT_DEV void trace_persistent(const SceneDev& sc, const Work& work, uint32_t n, u
                 work.load(mine, r.o, r.d, tmax);
                 r.inv = f3{1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z};
                 r.t = tmax; r.u = 0.0f; r.v = 0.0f; r.prim = kNoPrim;
-                r.item = mine; r.sp = 0;
+                r.item = mine; r.sp = 0; r.tos = kDone;
                 r.cur = sc.root_ref == kRefNone ? kDone : sc.root_ref;
                 live = true;
             }
             chunk_pos += n_idle < avail ? n_idle : avail;
         }
-        if (!__any(live)) {
+        if (__builtin_amdgcn_ballot_w64(live) == 0ull) {
             if (drained) break;
             continue;
         }
         // phase A: interior nodes, until enough lanes are parked on a leaf (or no lane has a node left)
         for (;;) {
-            bool at_node = live && r.cur < kDone;
-            if (!__any(at_node)) break;
-            if (uint32_t(__popcll(__ballot(live && (r.cur & kLeafBit) != 0u))) >= kLeafBatch) break;
+            const bool at_node = r.cur < kDone;            // lanes without a ray hold kDone
+            if (__builtin_amdgcn_ballot_w64(at_node) == 0ull) break;
+            if (uint32_t(__popcll(__builtin_amdgcn_ballot_w64(int32_t(r.cur) < 0))) >= kLeafBatch) break;
+#if defined(RT_PROBE_UTIL)
+            if (COUNT) ++n_node;       // utilisation probe: every lane counts every phase-A iteration of its wave
+#endif
             if (at_node) {
+#if !defined(RT_PROBE_UTIL)
                 if (COUNT) ++n_node;
-                node_step(sc, r, stack, spill);
+#endif
+                node_step(sc, r, stack, spill, hot);
             }
         }
         // phase B: the parked leaves
-        if (live && (r.cur & kLeafBit)) {
+#if defined(RT_PROBE_UTIL)
+        if (COUNT) {                    // utilisation probe: lane-slots spent in the leaf phase = 64 x the longest leaf of the wave
+            uint32_t mine = (live && (r.cur & kLeafBit)) ? ((r.cur >> 25) & 63u) + 1u : 0u;
+            for (int off = 32; off > 0; off >>= 1) mine = max(mine, (uint32_t)__shfl_xor(mine, off));
+            n_tri += mine;
+            if (mine) ++n_leaf;
+        }
+#endif
+        if (int32_t(r.cur) < 0) {
+#if !defined(RT_PROBE_UTIL)
             if (COUNT) ++n_leaf;
+#endif
             uint32_t first = r.cur & 0x01FFFFFFu;
             uint32_t count = ((r.cur >> 25) & 63u) + 1u;
             for (uint32_t k = 0; k < count; ++k) {
+#if !defined(RT_PROBE_UTIL)
                 if (COUNT) ++n_tri;
+#endif
                 triangle_test(sc, r, first + k);
                 if (ANYHIT && r.prim != kNoPrim) break;
             }
             // ANYHIT: the caller only asks whether anything lies nearer than the initial distance, so the first hit ends the ray
-            if (ANYHIT && r.prim != kNoPrim) { r.cur = kDone; r.sp = 0; }
-            else r.cur = stack_pop(stack, spill, r.sp);
+            if (ANYHIT && r.prim != kNoPrim) { r.cur = kDone; r.tos = kDone; r.sp = 0; }
+            else r.cur = stack_pop(stack, spill, r, false);
         }
         if (live && r.cur == kDone) {
             work.store(r.item, r);
@@ -355,6 +455,13 @@ __global__ __launch_bounds__(kBlock) void k_raygen(rt_camera cam, PathDev pd, ui
         if (seeds_out) seeds_out[slot] = seed;
     }
 }
+
+// LDS of a traversal workgroup: the per-lane stack heads and the resident node records (filled before any ray is traced).
+#define RT_TRACE_LDS                                                                      \
+    __shared__ uint32_t s_stack[kStackLds * kTraceBlock];                                 \
+    __shared__ v4f s_hot[kHotLds ? kHotLds * 4 : 1];                                      \
+    const HotNodes hot{(const lds_v4f*)s_hot, sc.n_hot < kHotLds ? sc.n_hot : kHotLds};   \
+    if (kHotLds) load_hot_nodes(sc, s_hot, hot.n);
 
 struct ExtendWork {
     PathDev pd;
@@ -411,14 +518,14 @@ RT_DEV void flush_counts(uint32_t n_node, uint32_t n_leaf, uint32_t n_tri, unsig
 
 // extend: closest hit for every queued slot (a persistent grid; `cursor` hands out queue entries).
 template <bool COUNT>
-__global__ __launch_bounds__(kTraceBlock) void k_extend(SceneDev sc, PathDev pd, const uint32_t* __restrict__ queue,
+__global__ __launch_bounds__(kTraceBlock, RT_TRACE_WAVES_PER_EU) void k_extend(SceneDev sc, PathDev pd, const uint32_t* __restrict__ queue,
                                                    const uint32_t* __restrict__ count_ptr, uint32_t count_imm,
                                                    uint32_t* cursor, TraceStats* stats) {
-    __shared__ uint32_t s_stack[kStackLds * kTraceBlock];
+    RT_TRACE_LDS
     const uint32_t n = count_ptr ? *count_ptr : count_imm;
     uint32_t n_node = 0, n_leaf = 0, n_tri = 0;
     ExtendWork work{pd, queue};
-    trace_persistent<COUNT, false>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, n_node, n_leaf, n_tri);
+    trace_persistent<COUNT, false>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, hot, n_node, n_leaf, n_tri);
     flush_counts<COUNT>(n_node, n_leaf, n_tri, &stats->extend_node_pops, &stats->extend_leaf_pops, &stats->extend_tri_tests);
 }
 
@@ -426,13 +533,13 @@ __global__ __launch_bounds__(kTraceBlock) void k_extend(SceneDev sc, PathDev pd,
 // When no material of the scene is glass-like (spec_trans > 0.5) "the closest hit is opaque" is the same predicate as
 // "there is a hit", so the query stops at the first hit (ANYHIT); with glass present the closest hit decides.
 template <bool COUNT, bool ANYHIT>
-__global__ __launch_bounds__(kTraceBlock) void k_connect(SceneDev sc, PathDev pd, ShadowQueue sq,
+__global__ __launch_bounds__(kTraceBlock, RT_TRACE_WAVES_PER_EU) void k_connect(SceneDev sc, PathDev pd, ShadowQueue sq,
                                                     const uint32_t* __restrict__ count_ptr, uint32_t* cursor, TraceStats* stats) {
-    __shared__ uint32_t s_stack[kStackLds * kTraceBlock];
+    RT_TRACE_LDS
     const uint32_t n = *count_ptr;
     uint32_t n_node = 0, n_leaf = 0, n_tri = 0;
     ConnectWork work{sc, pd, sq};
-    trace_persistent<COUNT, ANYHIT>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, n_node, n_leaf, n_tri);
+    trace_persistent<COUNT, ANYHIT>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, hot, n_node, n_leaf, n_tri);
     flush_counts<COUNT>(n_node, n_leaf, n_tri, &stats->shadow_node_pops, &stats->shadow_leaf_pops, &stats->shadow_tri_tests);
 }
 
@@ -831,14 +938,14 @@ struct RayListWork {
 };
 
 template <bool COUNT>
-__global__ __launch_bounds__(kTraceBlock) void k_trace_rays(SceneDev sc, const float4* __restrict__ ro, const float4* __restrict__ rd,
+__global__ __launch_bounds__(kTraceBlock, RT_TRACE_WAVES_PER_EU) void k_trace_rays(SceneDev sc, const float4* __restrict__ ro, const float4* __restrict__ rd,
                                                        uint32_t n, int shadow, float4* __restrict__ hits, uint32_t* cursor,
                                                        TraceStats* stats) {
-    __shared__ uint32_t s_stack[kStackLds * kTraceBlock];
+    RT_TRACE_LDS
     uint32_t n_node = 0, n_leaf = 0, n_tri = 0;
     RayListWork work{sc, ro, rd, hits, shadow};
-    if (shadow && !sc.has_glass) trace_persistent<COUNT, true>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, n_node, n_leaf, n_tri);
-    else trace_persistent<COUNT, false>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, n_node, n_leaf, n_tri);
+    if (shadow && !sc.has_glass) trace_persistent<COUNT, true>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, hot, n_node, n_leaf, n_tri);
+    else trace_persistent<COUNT, false>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, hot, n_node, n_leaf, n_tri);
     if (shadow) flush_counts<COUNT>(n_node, n_leaf, n_tri, &stats->shadow_node_pops, &stats->shadow_leaf_pops, &stats->shadow_tri_tests);
     else flush_counts<COUNT>(n_node, n_leaf, n_tri, &stats->extend_node_pops, &stats->extend_leaf_pops, &stats->extend_tri_tests);
 }
