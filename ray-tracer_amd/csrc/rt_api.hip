@@ -46,9 +46,10 @@ struct DevBuf {
 };
 
 #ifndef RT_DYNAMIC
-#define RT_DYNAMIC 0
+#define RT_DYNAMIC 1
 #endif
-// Work distribution of the traversal kernels: a device-wide cursor (dynamic) or block-strided batches of 64 neighbouring items.
+// Work distribution of the traversal kernels: block-strided chunks of neighbouring items, with (1) or without (0) a
+// device-wide cursor that hands out the tail of each list dynamically.
 #define RT_CURSOR(p) (RT_DYNAMIC ? (p) : nullptr)
 // Grid sizes in 256-thread units per CU. Traversal runs RT_TRACE_WAVES_PER_EU waves per SIMD (the LDS each workgroup
 // needs for stack heads and resident node records sets how many fit); shading is bound by HBM, and two workgroups per
@@ -215,7 +216,7 @@ int alloc_paths(rt_ctx* c) {
     uint32_t fpp = c->fpp_cfg;
     if (c->flags & RT_REF_RGBA8_ACCUM) fpp = 1;
     if (fpp == 0) {
-        const uint64_t target = 16ull << 20;  // ~16 M paths per lane keep every CU fed through the late, sparse bounces (~2 GiB of path state each)
+        const uint64_t target = 64ull << 20;  // ~64 M paths per lane keep every CU fed through the late, sparse bounces (~10 GiB of path state and queues each)
         fpp = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(64, target / std::max<uint32_t>(1, c->npix))));
     }
     c->fpp = fpp;
@@ -572,9 +573,14 @@ extern "C" int rt_render(rt_ctx* c, uint32_t n_samples) {
     // everything queued on the main stream so far (clears, uploads, stage-level calls) precedes this call's passes
     HIPCHK(c, hipEventRecord(c->call_mark, c->stream));
     for (uint32_t i = 0; i < c->n_lanes; ++i) HIPCHK(c, hipStreamWaitEvent(c->lanes[i].stream, c->call_mark, 0));
+    // Split the call into passes of at most fpp frames, as even as possible and at least one per lane, so that short
+    // calls still overlap two passes and long ones run the largest passes the path buffers hold (fewer, longer launches:
+    // less time in the ramp-down of each persistent traversal grid).
+    uint32_t n_pass = std::max<uint32_t>((n_samples + c->fpp - 1) / c->fpp, std::min<uint32_t>(c->n_lanes, n_samples));
     uint32_t left = n_samples;
     while (left) {
-        uint32_t frames = std::min(left, c->fpp);
+        uint32_t frames = (left + n_pass - 1) / n_pass;
+        --n_pass;
         uint32_t frame_first = c->slice_first + c->local_frame * c->slice_stride;
         Lane& l = c->lanes[c->next_lane];
         c->next_lane = (c->next_lane + 1) % c->n_lanes;

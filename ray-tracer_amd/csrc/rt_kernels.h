@@ -32,6 +32,12 @@ constexpr uint32_t kTraceBlock = RT_TRACE_BLOCK;   // workgroup size of the trav
 #ifndef RT_CHUNK
 #define RT_CHUNK 256
 #endif
+#ifndef RT_TAIL_SHIFT
+#define RT_TAIL_SHIFT 3
+#endif
+#ifndef RT_TAIL_CHUNK
+#define RT_TAIL_CHUNK 64
+#endif
 #ifndef RT_LEAF_BATCH
 #define RT_LEAF_BATCH 16
 #endif
@@ -320,28 +326,37 @@ RT_DEV void trace_persistent(const SceneDev& sc, const Work& work, uint32_t n, u
     bool live = false;
     bool drained = false;       // wave-uniform: the cursor has passed the end of the work list
     const uint32_t lane = lane_id();
-    // Work is handed out in chunks of kChunk consecutive items (neighbouring pixels / queue entries): a wave refills its
-    // idle lanes from its current chunk, so the rays it holds stay spatially close, and takes a new chunk from the
-    // device-wide cursor only when the current one is used up (or, without a cursor, from a block-strided sequence).
+    // Work is handed out in chunks of consecutive items (neighbouring pixels / queue entries): a wave refills its idle
+    // lanes from its current chunk, so the rays it holds stay spatially close. The first part of the list is dealt out
+    // statically (chunk k goes to wave k mod #waves: no shared counter); the last 1/2^RT_TAIL_SHIFT of it is handed out
+    // through the device-wide cursor in small chunks, so waves that finish their share early take over work from slow
+    // ones and the grid runs down together. Without a cursor the whole list is static.
     uint32_t chunk_pos = 0, chunk_end = 0;                                   // wave-uniform
     uint32_t next_static = ((blockIdx.x * kTraceBlock + threadIdx.x) >> 6) * kChunk;
     const uint32_t static_stride = (gridDim.x * kTraceBlock >> 6) * kChunk;
+    const uint32_t n_static = cursor ? ((n - (n >> RT_TAIL_SHIFT)) / kChunk) * kChunk : n;
+    bool static_done = false;
     for (;;) {
         unsigned long long idle = __builtin_amdgcn_ballot_w64(!live);
         uint32_t n_idle = uint32_t(__popcll(idle));
         if (!drained && n_idle >= kRefillAt) {
             if (chunk_pos >= chunk_end) {
-                uint32_t base = 0;
-                if (cursor) {
-                    if (lane == 0) base = atomicAdd(cursor, kChunk);
-                    base = __shfl(base, 0);
-                } else {
-                    base = next_static;
+                if (!static_done) {
+                    chunk_pos = next_static;
+                    chunk_end = chunk_pos + kChunk < n_static ? chunk_pos + kChunk : n_static;
                     next_static += static_stride;
+                    if (chunk_pos >= n_static) static_done = true;
                 }
-                chunk_pos = base;
-                chunk_end = base + kChunk < n ? base + kChunk : n;
-                if (base >= n) { drained = true; chunk_pos = chunk_end = 0; }
+                if (static_done) {
+                    uint32_t base = n;
+                    if (cursor) {
+                        if (lane == 0) base = n_static + atomicAdd(cursor, uint32_t(RT_TAIL_CHUNK));
+                        base = __shfl(base, 0);
+                    }
+                    chunk_pos = base;
+                    chunk_end = base + RT_TAIL_CHUNK < n ? base + RT_TAIL_CHUNK : n;
+                    if (base >= n) { drained = true; chunk_pos = chunk_end = 0; }
+                }
             }
             uint32_t avail = chunk_end - chunk_pos;
             uint32_t rank = uint32_t(__popcll(idle & ((1ull << lane) - 1ull)));
@@ -366,35 +381,18 @@ RT_DEV void trace_persistent(const SceneDev& sc, const Work& work, uint32_t n, u
             const bool at_node = r.cur < kDone;            // lanes without a ray hold kDone
             if (__builtin_amdgcn_ballot_w64(at_node) == 0ull) break;
             if (uint32_t(__popcll(__builtin_amdgcn_ballot_w64(int32_t(r.cur) < 0))) >= kLeafBatch) break;
-#if defined(RT_PROBE_UTIL)
-            if (COUNT) ++n_node;       // utilisation probe: every lane counts every phase-A iteration of its wave
-#endif
             if (at_node) {
-#if !defined(RT_PROBE_UTIL)
                 if (COUNT) ++n_node;
-#endif
                 node_step(sc, r, stack, spill, hot);
             }
         }
         // phase B: the parked leaves
-#if defined(RT_PROBE_UTIL)
-        if (COUNT) {                    // utilisation probe: lane-slots spent in the leaf phase = 64 x the longest leaf of the wave
-            uint32_t mine = (live && (r.cur & kLeafBit)) ? ((r.cur >> 25) & 63u) + 1u : 0u;
-            for (int off = 32; off > 0; off >>= 1) mine = max(mine, (uint32_t)__shfl_xor(mine, off));
-            n_tri += mine;
-            if (mine) ++n_leaf;
-        }
-#endif
         if (int32_t(r.cur) < 0) {
-#if !defined(RT_PROBE_UTIL)
             if (COUNT) ++n_leaf;
-#endif
             uint32_t first = r.cur & 0x01FFFFFFu;
             uint32_t count = ((r.cur >> 25) & 63u) + 1u;
             for (uint32_t k = 0; k < count; ++k) {
-#if !defined(RT_PROBE_UTIL)
                 if (COUNT) ++n_tri;
-#endif
                 triangle_test(sc, r, first + k);
                 if (ANYHIT && r.prim != kNoPrim) break;
             }

@@ -1,10 +1,9 @@
 #!/bin/bash
-for f in "$@"; do
-  timeout -k 10 300 python -u bench.py --steps 16 --warmup 4 --no-cpu-baseline --frames-per-pass $f > gpurun_out/fpp_$f.json 2> gpurun_out/fpp_$f.err || { echo "fpp $f failed"; tail -3 gpurun_out/fpp_$f.err; exit 1; }
-  python3 - <<PY
-import json
-d=json.load(open("gpurun_out/fpp_$f.json"))
-k=d["kernel_ms_per_sample"]
-print("fpp %-3s Mrays/s %7.1f  ms/step %6.3f | extend %.3f shade %.3f connect %.3f | ext %.0f Mr/s" % ("$f", d["value"], d["ms_per_step"], k["extend"], k["shade"], k["connect"], d["roofline"]["extend_mrays_per_s"]))
-PY
+# Usage: tools/fpp_bench.sh <frames per pass>...   -- bench.py with passes of that many frames (steps = 8 passes)
+mkdir -p gpurun_out
+for F in "$@"; do
+  S=$((F * 8))
+  timeout -k 10 300 python -u bench.py --steps $S --warmup $F --no-cpu-baseline --no-roofline --frames-per-pass $F > gpurun_out/fpp_$F.json 2> gpurun_out/fpp_$F.err || { echo "fpp $F failed"; tail -3 gpurun_out/fpp_$F.err; exit 1; }
+  python3 -c "
+import json; d=json.load(open('gpurun_out/fpp_$F.json')); print('frames/pass $F: Mrays/s %.1f samples/s %.2f ms/step %.3f' % (d['value'], d['samples_per_sec'], d['ms_per_step']))"
 done

@@ -6,7 +6,7 @@ timeout -k 10 600 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout
 rc=$?
 tail -5 gpurun_out/gputests_$TAG.log
 if [ $rc -ne 0 ]; then echo "tests failed rc=$rc"; grep -n "Error\|assert\|FAILED" gpurun_out/gputests_$TAG.log | head -30; exit $rc; fi
-timeout -k 10 400 python -u bench.py --steps 16 --warmup 2 --no-cpu-baseline "$@" > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err || { echo bench failed; tail -5 gpurun_out/bench_$TAG.err; exit 1; }
+timeout -k 10 400 python -u bench.py --steps 64 --warmup 8 --no-cpu-baseline "$@" > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err || { echo bench failed; tail -5 gpurun_out/bench_$TAG.err; exit 1; }
 python3 - <<PY
 import json
 d=json.load(open("gpurun_out/bench_$TAG.json"))
