@@ -24,7 +24,7 @@ constexpr uint32_t kTraceBlock = RT_TRACE_BLOCK;   // workgroup size of the trav
 #define RT_STACK_LDS 8
 #endif
 #ifndef RT_REFILL_AT
-#define RT_REFILL_AT 24
+#define RT_REFILL_AT 8
 #endif
 #ifndef RT_SHADE_WAVES
 #define RT_SHADE_WAVES 1
@@ -38,11 +38,14 @@ constexpr uint32_t kTraceBlock = RT_TRACE_BLOCK;   // workgroup size of the trav
 #ifndef RT_TAIL_CHUNK
 #define RT_TAIL_CHUNK 64
 #endif
+#ifndef RT_COOP_ANYHIT
+#define RT_COOP_ANYHIT 0
+#endif
 #ifndef RT_LEAF_BATCH
-#define RT_LEAF_BATCH 16
+#define RT_LEAF_BATCH 12
 #endif
 #ifndef RT_HOT_LDS
-#define RT_HOT_LDS 768
+#define RT_HOT_LDS 752
 #endif
 #ifndef RT_TRACE_WAVES_PER_EU
 #define RT_TRACE_WAVES_PER_EU 8
@@ -278,30 +281,89 @@ RT_DEV void node_step(const SceneDev& sc, LaneRay& r, lds_u32* stack, uint32_t* 
 }
 
 // Moeller-Trumbore exactly as hit_triangle evaluates it (intersects.comp:37-64) on the 48-byte record
-// {v0, n.x} {v1-v0, n.y} {v2-v0, n.z}.
-RT_DEV void triangle_test(const SceneDev& sc, LaneRay& r, uint32_t tri) {
+// {v0, n.x} {v1-v0, n.y} {v2-v0, n.z}. Returns false when the shader would have returned early; t may be NaN
+// (degenerate triangle), which then loses every "closer than" comparison, as there.
+RT_DEV bool triangle_test(const SceneDev& sc, f3 o, f3 d, uint32_t tri, float& t, float& u, float& v) {
     // 32-bit byte offset (the 48-byte records of at most 2^25 triangles stay below 4 GiB): scalar base + lane offset addressing
     const float4* tp = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sc.isect) + tri * 48u);
     float4 A = tp[0], B = tp[1], C = tp[2];        // all 48 bytes requested at once: one round trip per triangle
     f3 pn = {A.w, B.w, C.w};
-    float ndd = dot(pn, r.d);
+    float ndd = dot(pn, d);
     f3 ab = xyz(B), ac = xyz(C);
-    f3 oo = r.o - xyz(A);
-    f3 p = cross(r.d, ac);
+    f3 oo = o - xyz(A);
+    f3 p = cross(d, ac);
     f3 q = cross(oo, ab);
     float inv_det = 1.0f / dot(p, ab);
-    float t = dot(q, ac) * inv_det;
-    float u = dot(p, oo) * inv_det;
-    float v = dot(q, r.d) * inv_det;
+    t = dot(q, ac) * inv_det;
+    u = dot(p, oo) * inv_det;
+    v = dot(q, d) * inv_det;
     float w = 1.0f - u - v;
     // the shader's chain of early returns (intersects.comp:42,52,61), evaluated without branches; every comparison is
     // written exactly as there, so NaNs fall through the same way
     bool reject = (fabsf(ndd) < kRayEps) | (t < kRayEps) | (u < 0.0f) | (v < 0.0f) | (w < 0.0f) | (u > 1.0f) | (v > 1.0f) | (w > 1.0f);
-    bool take = !reject & (t < r.t);
-    r.t = take ? t : r.t;
-    r.u = take ? u : r.u;
-    r.v = take ? v : r.v;
-    r.prim = take ? tri : r.prim;
+    return !reject;
+}
+
+RT_DEV float wave_pull(uint32_t src_lane, float v) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(int(src_lane << 2), __float_as_int(v)));
+}
+RT_DEV uint32_t wave_pull(uint32_t src_lane, uint32_t v) {
+    return uint32_t(__builtin_amdgcn_ds_bpermute(int(src_lane << 2), int(v)));
+}
+
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+
+// Leaf phase, executed by the whole wavefront (all 64 lanes active) for the P lanes parked on a leaf. A leaf holds two
+// or three triangles on average and only a quarter of the lanes are parked when the phase starts, so the lanes are
+// regrouped: with P <= 16 the wave forms 4 columns of 16 slots, slot p of column c tests triangle c of the p-th parked
+// lane's leaf (P <= 32: 2 columns, else 1), on ray data pulled from the owner with ds_bpermute. The owner then folds
+// its columns in triangle order with the shader's strict "closer" test (intersects.comp:141-150), so the first triangle
+// tested still wins an exact tie. `slot_owner` is this wave's 64-byte LDS strip.
+template <bool COUNT, bool ANYHIT>
+RT_DEV void leaf_phase(const SceneDev& sc, LaneRay& r, unsigned long long parked_mask, lds_u8* slot_owner, lds_u32* stack, uint32_t* spill,
+                       uint32_t& n_leaf, uint32_t& n_tri) {
+    const uint32_t lane = lane_id();
+    const bool parked = int32_t(r.cur) < 0;
+    const uint32_t P = uint32_t(__popcll(parked_mask));
+    const uint32_t rank = uint32_t(__popcll(parked_mask & ((1ull << lane) - 1ull)));
+    const uint32_t shift = P <= 16u ? 4u : (P <= 32u ? 5u : 6u);      // wave-uniform
+    const uint32_t columns = 64u >> shift;
+    const uint32_t slot = lane & ((1u << shift) - 1u), col = lane >> shift;
+    if (parked) slot_owner[rank] = uint8_t(lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // same wave: LDS operations complete in order
+    const bool slot_used = slot < P;
+    const uint32_t owner = slot_used ? uint32_t(slot_owner[slot]) : lane;
+    const f3 o = {wave_pull(owner, r.o.x), wave_pull(owner, r.o.y), wave_pull(owner, r.o.z)};
+    const f3 d = {wave_pull(owner, r.d.x), wave_pull(owner, r.d.y), wave_pull(owner, r.d.z)};
+    const uint32_t leaf = wave_pull(owner, r.cur);
+    const uint32_t first = leaf & 0x01FFFFFFu, count = ((leaf >> 25) & 63u) + 1u;
+    const uint32_t my_first = r.cur & 0x01FFFFFFu;
+    if (COUNT && parked) { ++n_leaf; n_tri += ((r.cur >> 25) & 63u) + 1u; }
+    for (uint32_t base = 0;; base += columns) {
+        const bool mine = slot_used && base + col < count;
+        if (__builtin_amdgcn_ballot_w64(mine) == 0ull) break;
+        float t = INFINITY, u = 0.0f, v = 0.0f;
+        bool ok = false;
+        if (mine) ok = triangle_test(sc, o, d, first + base + col, t, u, v);
+        const float t_res = ok ? t : INFINITY;        // NaN stays NaN and loses the comparison below
+        // owners: fold the columns in triangle order
+        float best_t = r.t;
+        uint32_t best_col = 0xFFFFFFFFu;
+        for (uint32_t c = 0; c < columns; ++c) {
+            float tc = wave_pull(rank + (c << shift), t_res);
+            if (tc < best_t) { best_t = tc; best_col = c; }
+        }
+        const uint32_t win = rank + ((best_col & 3u) << shift);
+        const float bu = wave_pull(win, u), bv = wave_pull(win, v);
+        if (parked && best_col != 0xFFFFFFFFu) {
+            r.t = best_t; r.u = bu; r.v = bv; r.prim = my_first + base + best_col;
+        }
+    }
+    if (parked) {
+        // ANYHIT: the caller only asks whether anything lies nearer than the initial distance, so a hit ends the ray
+        if (ANYHIT && r.prim != kNoPrim) { r.cur = kDone; r.tos = kDone; r.sp = 0; }
+        else r.cur = stack_pop(stack, spill, r, false);
+    }
 }
 
 // Work description for the persistent tracer: how item i becomes a ray and where its result goes.
@@ -309,8 +371,8 @@ RT_DEV void triangle_test(const SceneDev& sc, LaneRay& r, uint32_t tri) {
 // ANYHIT turns the closest-hit search into an occlusion query (stop at the first hit below tmax).
 //   void store(uint32_t i, const LaneRay& r)
 template <bool COUNT, bool ANYHIT, class Work>
-RT_DEV void trace_persistent(const SceneDev& sc, const Work& work, uint32_t n, uint32_t* cursor, lds_u32* stack, const HotNodes& hot,
-                             uint32_t& n_node, uint32_t& n_leaf, uint32_t& n_tri) {
+RT_DEV void trace_persistent(const SceneDev& sc, const Work& work, uint32_t n, uint32_t* cursor, lds_u32* stack, lds_u8* slot_owner,
+                             const HotNodes& hot, uint32_t& n_node, uint32_t& n_leaf, uint32_t& n_tri) {
     constexpr uint32_t kRefillAt = RT_REFILL_AT;     // refill once this many lanes sit idle
     // consecutive work items a wave owns at a time: RT_CHUNK when there is plenty of work, down to 64 when the queue is
     // short (late bounces), so every resident wave still gets a share
@@ -387,18 +449,22 @@ RT_DEV void trace_persistent(const SceneDev& sc, const Work& work, uint32_t n, u
             }
         }
         // phase B: the parked leaves
-        if (int32_t(r.cur) < 0) {
-            if (COUNT) ++n_leaf;
-            uint32_t first = r.cur & 0x01FFFFFFu;
-            uint32_t count = ((r.cur >> 25) & 63u) + 1u;
-            for (uint32_t k = 0; k < count; ++k) {
-                if (COUNT) ++n_tri;
-                triangle_test(sc, r, first + k);
-                if (ANYHIT && r.prim != kNoPrim) break;
+        {
+            const unsigned long long parked_mask = __builtin_amdgcn_ballot_w64(int32_t(r.cur) < 0);
+            if (RT_COOP_ANYHIT || !ANYHIT) {
+                if (parked_mask != 0ull) leaf_phase<COUNT, ANYHIT>(sc, r, parked_mask, slot_owner, stack, spill, n_leaf, n_tri);
+            } else if (int32_t(r.cur) < 0) {
+                // occlusion queries: each parked lane walks its own leaf and stops at the first hit
+                if (COUNT) ++n_leaf;
+                const uint32_t first = r.cur & 0x01FFFFFFu, count = ((r.cur >> 25) & 63u) + 1u;
+                for (uint32_t k = 0; k < count; ++k) {
+                    if (COUNT) ++n_tri;
+                    float t, u, v;
+                    if (triangle_test(sc, r.o, r.d, first + k, t, u, v) && t < r.t) { r.t = t; r.u = u; r.v = v; r.prim = first + k; break; }
+                }
+                if (r.prim != kNoPrim) { r.cur = kDone; r.tos = kDone; r.sp = 0; }
+                else r.cur = stack_pop(stack, spill, r, false);
             }
-            // ANYHIT: the caller only asks whether anything lies nearer than the initial distance, so the first hit ends the ray
-            if (ANYHIT && r.prim != kNoPrim) { r.cur = kDone; r.tos = kDone; r.sp = 0; }
-            else r.cur = stack_pop(stack, spill, r, false);
         }
         if (live && r.cur == kDone) {
             work.store(r.item, r);
@@ -457,6 +523,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen(rt_camera cam, PathDev pd, ui
 // LDS of a traversal workgroup: the per-lane stack heads and the resident node records (filled before any ray is traced).
 #define RT_TRACE_LDS                                                                      \
     __shared__ uint32_t s_stack[kStackLds * kTraceBlock];                                 \
+    __shared__ uint8_t s_owner[kTraceBlock];                                              \
     __shared__ v4f s_hot[kHotLds ? kHotLds * 4 : 1];                                      \
     const HotNodes hot{(const lds_v4f*)s_hot, sc.n_hot < kHotLds ? sc.n_hot : kHotLds};   \
     if (kHotLds) load_hot_nodes(sc, s_hot, hot.n);
@@ -523,7 +590,7 @@ __global__ __launch_bounds__(kTraceBlock, RT_TRACE_WAVES_PER_EU) void k_extend(S
     const uint32_t n = count_ptr ? *count_ptr : count_imm;
     uint32_t n_node = 0, n_leaf = 0, n_tri = 0;
     ExtendWork work{pd, queue};
-    trace_persistent<COUNT, false>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, hot, n_node, n_leaf, n_tri);
+    trace_persistent<COUNT, false>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, (lds_u8*)s_owner + (threadIdx.x & ~63u), hot, n_node, n_leaf, n_tri);
     flush_counts<COUNT>(n_node, n_leaf, n_tri, &stats->extend_node_pops, &stats->extend_leaf_pops, &stats->extend_tri_tests);
 }
 
@@ -537,7 +604,7 @@ __global__ __launch_bounds__(kTraceBlock, RT_TRACE_WAVES_PER_EU) void k_connect(
     const uint32_t n = *count_ptr;
     uint32_t n_node = 0, n_leaf = 0, n_tri = 0;
     ConnectWork work{sc, pd, sq};
-    trace_persistent<COUNT, ANYHIT>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, hot, n_node, n_leaf, n_tri);
+    trace_persistent<COUNT, ANYHIT>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, (lds_u8*)s_owner + (threadIdx.x & ~63u), hot, n_node, n_leaf, n_tri);
     flush_counts<COUNT>(n_node, n_leaf, n_tri, &stats->shadow_node_pops, &stats->shadow_leaf_pops, &stats->shadow_tri_tests);
 }
 
@@ -942,8 +1009,8 @@ __global__ __launch_bounds__(kTraceBlock, RT_TRACE_WAVES_PER_EU) void k_trace_ra
     RT_TRACE_LDS
     uint32_t n_node = 0, n_leaf = 0, n_tri = 0;
     RayListWork work{sc, ro, rd, hits, shadow};
-    if (shadow && !sc.has_glass) trace_persistent<COUNT, true>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, hot, n_node, n_leaf, n_tri);
-    else trace_persistent<COUNT, false>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, hot, n_node, n_leaf, n_tri);
+    if (shadow && !sc.has_glass) trace_persistent<COUNT, true>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, (lds_u8*)s_owner + (threadIdx.x & ~63u), hot, n_node, n_leaf, n_tri);
+    else trace_persistent<COUNT, false>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, (lds_u8*)s_owner + (threadIdx.x & ~63u), hot, n_node, n_leaf, n_tri);
     if (shadow) flush_counts<COUNT>(n_node, n_leaf, n_tri, &stats->shadow_node_pops, &stats->shadow_leaf_pops, &stats->shadow_tri_tests);
     else flush_counts<COUNT>(n_node, n_leaf, n_tri, &stats->extend_node_pops, &stats->extend_leaf_pops, &stats->extend_tri_tests);
 }
