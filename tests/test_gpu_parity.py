@@ -11,7 +11,7 @@ from pathlib import Path
 import numpy as np
 import pytest
 
-from util import chain_scene, random_rays, rel_close
+from util import chain_scene, random_rays, rel_close, two_leaf_scene
 
 pytestmark = pytest.mark.gpu
 GOLD = Path(__file__).resolve().parent / "golden"
@@ -176,6 +176,61 @@ def test_trees_deeper_than_the_stack_bound_are_rejected(rt, oracle):
     r.destroy()
     with pytest.raises(RuntimeError, match="deeper than 64"):
         rt.HipRenderer.create(chain_scene(65), max_bounces=2)
+
+
+@pytest.mark.parametrize("n_rays", [1, 7, 16, 17, 30, 33, 64, 65, 1000, 20000])
+def test_leaf_phase_lane_regrouping_keeps_triangle_order(rt, oracle, n_rays):
+    """The leaf phase spreads the triangles of the parked lanes over 4, 2 or 1 columns of the wavefront depending on how
+    many lanes are parked, and walks leaves larger than the column count in several rounds: ids, distances and
+    barycentrics equal the per-ray loop of the oracle, including exact ties between a triangle and its duplicate."""
+    sc = two_leaf_scene()
+    r = rt.HipRenderer.create(sc, max_bounces=2, flags=rt.api.RT_COUNT_TRAVERSAL)
+    o = oracle.OracleScene(sc)
+    rng = np.random.default_rng(100 + n_rays)
+    ro = np.stack([rng.uniform(-2, 2, n_rays), rng.uniform(-1, 1, n_rays), np.full(n_rays, 3.0)], 1).astype(np.float32)
+    rd = np.stack([rng.normal(0, 0.15, n_rays), rng.normal(0, 0.15, n_rays), np.full(n_rays, -1.0)], 1)
+    rd = (rd / np.linalg.norm(rd, axis=1, keepdims=True)).astype(np.float32)
+    r.reset_counters()
+    g = r.trace_closest(ro, rd)
+    h, cnt = o.trace_closest(ro, rd)
+    assert np.array_equal(g["prim"], h["prim"]) and np.array_equal(g["t"], h["t"])
+    assert np.array_equal(g["u"], h["u"]) and np.array_equal(g["v"], h["v"])
+    c = r.counters()
+    assert (c["extend_node_pops"], c["extend_leaf_pops"], c["extend_tri_tests"]) == (cnt["node_pops"], cnt["leaf_pops"], cnt["tri_tests"])
+    if n_rays >= 1000:
+        hit = g["prim"] != 0xFFFFFFFF
+        assert hit.mean() > 0.1
+        tris = sc.triangles["v"][..., :3]
+        dup_second = np.array([k for k in range(1, len(tris)) if np.array_equal(tris[k], tris[k - 1])])
+        assert not np.isin(g["prim"][hit], dup_second).any()      # the first copy of a duplicated triangle always wins
+    tmax = rng.uniform(1.0, 6.0, n_rays).astype(np.float32)
+    assert np.array_equal(r.trace_shadow(ro, rd, tmax), o.trace_shadow(ro, rd, tmax))
+    r.destroy()
+
+
+def test_lds_resident_node_prefix_does_not_change_results(rt, oracle, scene_cache, monkeypatch):
+    """The traversal kernels keep the largest-area node records in LDS. Uploading the same scene with that prefix
+    disabled (every record fetched from global memory) gives identical hits, and both equal the oracle."""
+    sc = scene_cache("atrium", scale=0.05, width=96, height=54)
+    assert (sc.bvh["amt"] == 0).sum() > 2048            # more interior nodes than can be resident
+    o = oracle.OracleScene(sc)
+    rng = np.random.default_rng(23)
+    lo = sc.triangles["v"][..., :3].min(axis=(0, 1)) - 0.5
+    hi = sc.triangles["v"][..., :3].max(axis=(0, 1)) + 0.5
+    ro, rd = random_rays(rng, 30000, lo, hi)
+    h, _ = o.trace_closest(ro, rd)
+    results = []
+    for hot in ("0", "37", None):
+        if hot is None:
+            monkeypatch.delenv("RT_HIP_HOT_NODES", raising=False)
+        else:
+            monkeypatch.setenv("RT_HIP_HOT_NODES", hot)
+        r = rt.HipRenderer.create(sc, max_bounces=2)
+        results.append(r.trace_closest(ro, rd))
+        r.destroy()
+    for g in results:
+        assert np.array_equal(g["prim"], h["prim"]) and np.array_equal(g["t"], h["t"])
+        assert np.array_equal(g["u"], h["u"]) and np.array_equal(g["v"], h["v"])
 
 
 def test_extend_empty_scene_and_ragged_sizes(rt):

@@ -71,3 +71,39 @@ def rel_close(a, b, rtol, atol):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     both_nan = np.isnan(a) & np.isnan(b)
     return both_nan | (np.abs(a - b) <= atol + rtol * np.abs(b))
+
+
+def two_leaf_scene(n_left=40, n_right=64, seed=3):
+    """Root with two leaf children holding `n_left` and `n_right` small triangles (x < 0 and x > 0), every third triangle
+    repeated right after itself (an exact tie in distance: the first copy must win). All rays reach a leaf on their first
+    node visit, so the leaf phase sees anything from one to sixty-four lanes parked at once, on leaves far larger than
+    the number of triangle columns a wavefront forms."""
+    import numpy as np
+    from ray_tracer_amd import api
+    from ray_tracer_amd.scene import Scene, default_material, look_at_camera, make_triangles
+    rng = np.random.default_rng(seed)
+
+    def soup(n, x0):
+        out = []
+        while len(out) < n:
+            c = np.array([x0 + rng.uniform(-0.9, 0.9), rng.uniform(-0.9, 0.9), rng.uniform(-0.5, 0.5)])
+            tri = (c + rng.uniform(-0.35, 0.35, size=(3, 3))).astype(np.float32)
+            out.append(tri)
+            if len(out) % 3 == 0 and len(out) < n:
+                out.append(tri.copy())
+        return np.stack(out[:n])
+
+    left, right = soup(n_left, -1.0), soup(n_right, 1.0)
+    verts = np.concatenate([left, right]).astype(np.float32)
+    tris = make_triangles(verts, None, None, np.zeros(len(verts), np.uint32))
+    nodes = np.zeros(3, dtype=api.BVH_NODE)
+    nodes[0]["min"], nodes[0]["max"] = verts.min(axis=(0, 1)), verts.max(axis=(0, 1))
+    nodes[0]["idx"], nodes[0]["amt"] = 1, 0
+    nodes[1]["min"], nodes[1]["max"] = left.min(axis=(0, 1)), left.max(axis=(0, 1))
+    nodes[1]["idx"], nodes[1]["amt"] = 0, n_left
+    nodes[2]["min"], nodes[2]["max"] = right.min(axis=(0, 1)), right.max(axis=(0, 1))
+    nodes[2]["idx"], nodes[2]["amt"] = n_left, n_right
+    sc = Scene(triangles=tris, materials=default_material(1), camera=look_at_camera(8, 8, (0, 0, 4), (0, 0, 0)))
+    sc.bvh = nodes
+    sc.build_lights()
+    return sc

@@ -15,11 +15,11 @@ from ray_tracer_amd import scenes  # noqa: E402
 
 CONFIGS = [
     ("cornell", dict(width=256, height=256), 4, 16),
-    ("atrium", dict(width=1920, height=1080), 8, 32),
-    ("glass_blob", dict(width=1920, height=1080), 8, 16),
-    ("glass_blob", dict(width=1920, height=1080), 24, 16),
-    ("car", dict(width=1920, height=1080), 8, 16),
-    ("interior", dict(width=3840, height=2160), 8, 8),
+    ("atrium", dict(width=1920, height=1080), 8, 64),
+    ("glass_blob", dict(width=1920, height=1080), 8, 64),
+    ("glass_blob", dict(width=1920, height=1080), 24, 64),
+    ("car", dict(width=1920, height=1080), 8, 64),
+    ("interior", dict(width=3840, height=2160), 8, 16),
 ]
 
 
