@@ -179,7 +179,10 @@ def main():
 
     # ---- roofline of the dominant kernel (extend), rank 0 only: HIP-event time per launch, algorithmic bytes from traversal counters
     if rank == 0 and not args.no_roofline:
-        k = min(args.steps, 8)
+        # one pass of the same size as the timed region's passes (the library splits a call evenly over its two lanes, at most
+        # 32 frames of 1080p per pass), so these launches are the size of the ones the trace of the main run shows
+        lanes = int(os.environ.get("RT_HIP_LANES", "2"))
+        k = max(1, min(32, -(-args.steps // max(1, lanes))))
         rc = rt.HipRenderer.create(scene, max_bounces=args.bounces, device=local_rank, flags=api.RT_COUNT_TRAVERSAL,
                                    frames_per_pass=args.frames_per_pass)
         rc.render(k)
@@ -200,7 +203,7 @@ def main():
         # (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; tools/profile_gpu.sh). Counters cannot be read from inside this process.
         traffic = None
         prof = {}
-        tfile = ROOT / "profiles" / "r1_v3_traffic.json"
+        tfile = ROOT / "profiles" / "r1_v4_traffic.json"
         default_cfg = (args.scene == "atrium" and args.scale == 1.0 and (args.width, args.height, args.bounces) == (1920, 1080, 8)
                        and args.frames_per_pass == 0 and args.bvh == "spatial")
         if default_cfg and tfile.exists():
@@ -209,12 +212,13 @@ def main():
         result["roofline"] = {
             "kernel": "k_extend", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "traffic_note": "bytes per launch beyond L2 (Infinity Cache hits included), profiles/r1_v3_traffic.json; algorithmic bytes "
-                            "charge every node visit to HBM, so achieved may exceed the HBM peak when caches serve the BVH",
+            "traffic_note": "bytes per launch beyond L2 (Infinity Cache hits included), profiles/r1_v4_traffic.json; algorithmic bytes "
+                            "charge every node visit to HBM, so achieved exceeds the HBM peak: about 60 % of the node visits are "
+                            "served from LDS-resident records and most of the rest from L1/L2",
             "measured_in": "a separate context with per-kernel events (single stream: kernels run alone, as in the rocprofv3 "
                            "single-stream trace under profiles/); the timed region overlaps two passes, which lengthens individual launches",
             "l2_hit_rate": prof.get("l2_hit_rate"), "active_lanes_per_valu_instruction": prof.get("active_lanes_per_valu_instruction"),
-            "occupancy": "8 waves/SIMD (62 VGPRs, 16 KiB LDS per 256-thread workgroup, 8 workgroups per CU: every wave slot)",
+            "occupancy": "8 waves/SIMD (64 VGPRs; two 1024-thread workgroups per CU, 80 KiB LDS each: 32 KiB stack heads + 47 KiB resident node records)",
             "bytes_per_launch": b_ext / max(1, tm["extend_launches"]), "avg_launch_ms": tm["extend_ms"] / max(1, tm["extend_launches"]),
             "launches": tm["extend_launches"], "samples": k,
             "bytes_per_ray": b_ext / max(1, c["extend_rays"]),

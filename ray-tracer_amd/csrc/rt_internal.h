@@ -39,12 +39,19 @@ inline uint32_t make_leaf_ref(uint32_t first, uint32_t count) { return kLeafBit 
 struct alignas(16) TriIsect {
     float a[4], b[4], c[4];
 };
-// 64-byte shading record: n0 n1 n2 (9 floats), uv0 uv1 uv2 (6 floats), matword.
+// 64-byte shading record, ordered so that a vertex loads only the 16-byte chunks it needs:
+//   chunk 0 {n0.xyz, matword}   chunk 1 {n1.xyz, n2.x}   chunk 2 {n2.yz, uv0.xy}   chunk 3 {uv1.xy, uv2.xy}
+// flat untextured triangles need chunk 0, smooth ones chunks 0-2, textured ones all four.
 // matword = material index | bit 31: spec_trans > 0.5 | bit 30: shade_smooth.
 struct alignas(16) TriShade {
-    float n[9];
-    float uv[6];
+    float n0[3];
     uint32_t matword;
+    float n1[3];
+    float n2x;
+    float n2yz[2];
+    float uv0[2];
+    float uv1[2];
+    float uv2[2];
 };
 static_assert(sizeof(TriIsect) == 48 && sizeof(TriShade) == 64, "triangle streams");
 

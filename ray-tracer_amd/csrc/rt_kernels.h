@@ -61,7 +61,7 @@ constexpr uint32_t kMaxBounces = 64;
 struct SceneDev {
     const float4* __restrict__ nodes;     // 4 x float4 per interior record
     const float4* __restrict__ isect;     // 3 x float4 per triangle
-    const float4* __restrict__ shade;     // 4 x float4 per triangle
+    const float4* __restrict__ shade;     // 4 x float4 per triangle: {n0, matword} {n1, n2.x} {n2.yz, uv0} {uv1, uv2}
     const float4* __restrict__ mats;      // 6 x float4 per material
     const float4* __restrict__ lights;    // 3 x float4 per analytic light
     const float4* __restrict__ light_tris; // per emissive triangle: {v0, area} {v1, Le.r} {v2, Le.g} {unit normal, Le.b}
@@ -558,7 +558,7 @@ struct ConnectWork {
     }
     RT_DEV void store(uint32_t i, const LaneRay& r) const {
         bool blocked = false;
-        if (r.prim != kNoPrim) blocked = (__float_as_uint(sc.shade[size_t(r.prim) * 4 + 3].w) & 0x80000000u) == 0u;
+        if (r.prim != kNoPrim) blocked = (__float_as_uint(sc.shade[size_t(r.prim) * 4].w) & 0x80000000u) == 0u;
         if (!blocked) {
             uint32_t slot = sq.queue[i];
             float4 c = sq.c[slot];
@@ -668,11 +668,13 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_WAVES) void k_shade(SceneDev sc, P
                 rad = rad + f3{bg.x, bg.y, bg.z} * thr;
             } else {
                 const float t = h4.x, u = h4.y, v = h4.z, w = 1.0f - h4.y - h4.z;
-                const float4* ip = sc.isect + size_t(prim) * 3;
-                float4 A = ip[0], B = ip[1], C = ip[2];
+                // The kernel is bound by the rate at which scattered 16-byte loads return, so a vertex fetches only what
+                // it uses: chunk 0 of the shading record always (normal 0 + material word), the other normals for
+                // smooth-shaded triangles, the texture coordinates when the material binds a texture, and the 48-byte
+                // geometry record only for flat normals, tangent frames and the area of an emitter that was hit.
                 const float4* ap = sc.shade + size_t(prim) * 4;
-                float4 s0 = ap[0], s1 = ap[1], s2 = ap[2], s3 = ap[3];
-                uint32_t matword = __float_as_uint(s3.w);
+                const float4 s0 = ap[0];
+                const uint32_t matword = __float_as_uint(s0.w);
                 Mat m;
                 if (LDS_TABLES) {
                     const lds_v4f* mp = l_mats + (matword & 0x3FFFFFFFu) * 6;
@@ -680,14 +682,26 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_WAVES) void k_shade(SceneDev sc, P
                 } else {
                     m = load_material(sc.mats, matword & 0x3FFFFFFFu);
                 }
-                f3 untextured_emission = m.emission;
+                const f3 untextured_emission = m.emission;
+                const bool smooth = (matword & 0x40000000u) != 0u;
+                const bool textured = (m.base_tex & m.mr_tex & m.emission_tex & m.normal_tex) != 0xFFFFFFFFu;
+                const bool emitter_mis = sp.bounce > 0 && sc.n_emissive != 0 && num_lights != 0 && luminance(untextured_emission) > 0.0f;
+                const bool need_geometry = !smooth || m.normal_tex != 0xFFFFFFFFu || emitter_mis;
+                float4 s1 = {}, s2 = {}, s3 = {}, A = {}, B = {}, C = {};
+                if (smooth || textured) s2 = ap[2];
+                if (smooth) s1 = ap[1];
+                if (textured) s3 = ap[3];
+                if (need_geometry) {
+                    const float4* ip = sc.isect + size_t(prim) * 3;
+                    A = ip[0]; B = ip[1]; C = ip[2];
+                }
                 f3 ab = xyz(B), ac = xyz(C);
                 f3 pos = ro + rd * t;
-                float uvx = s2.y * w + s2.w * u + s3.y * v;
-                float uvy = s2.z * w + s3.x * u + s3.z * v;
+                float uvx = s2.z * w + s3.x * u + s3.z * v;
+                float uvy = s2.w * w + s3.y * u + s3.w * v;
                 f3 normal;
-                if (matword & 0x40000000u)
-                    normal = normalize(f3{s0.x, s0.y, s0.z} * w + f3{s0.w, s1.x, s1.y} * u + f3{s1.z, s1.w, s2.x} * v);
+                if (smooth)
+                    normal = normalize(f3{s0.x, s0.y, s0.z} * w + f3{s1.x, s1.y, s1.z} * u + f3{s1.w, s2.x, s2.y} * v);
                 else
                     normal = f3{A.w, B.w, C.w};
                 // texture modulation, main.comp:141-159
@@ -697,7 +711,7 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_WAVES) void k_shade(SceneDev sc, P
                 if (m.normal_tex != 0xFFFFFFFFu) {
                     f4 c = sample_2d(sc.tex, m.normal_tex, uvx, uvy);
                     f3 tn = f3{c.x, c.y, c.z} * 2.0f - mk3(1.0f);
-                    float d1x = s2.w - s2.y, d1y = s3.x - s2.z, d2x = s3.y - s2.y, d2y = s3.z - s2.z;  // intersects.comp:82-89
+                    float d1x = s3.x - s2.z, d1y = s3.y - s2.w, d2x = s3.z - s2.z, d2y = s3.w - s2.w;  // intersects.comp:82-89
                     float f = 1.0f / (d1x * d2y - d2x * d1y);
                     f3 tangent = normalize(f * (d2y * ab - d1y * ac));
                     f3 bitangent = normalize(f * (-d2x * ab + d1x * ac));
@@ -994,7 +1008,7 @@ struct RayListWork {
     }
     RT_DEV void store(uint32_t i, const LaneRay& r) const {
         if (shadow) {
-            bool blocked = r.prim != kNoPrim && (__float_as_uint(sc.shade[size_t(r.prim) * 4 + 3].w) & 0x80000000u) == 0u;
+            bool blocked = r.prim != kNoPrim && (__float_as_uint(sc.shade[size_t(r.prim) * 4].w) & 0x80000000u) == 0u;
             hits[i] = make_float4(blocked ? 0.0f : 1.0f, 0.0f, 0.0f, __uint_as_float(r.prim));
         } else {
             hits[i] = make_float4(r.t, r.u, r.v, __uint_as_float(r.prim));

@@ -51,9 +51,9 @@ int convert_scene(const rt_bvh_node* nodes, uint32_t n_nodes, const rt_triangle*
         q.b[0] = ab[0];     q.b[1] = ab[1];     q.b[2] = ab[2];     q.b[3] = cy * inv;
         q.c[0] = ac[0];     q.c[1] = ac[1];     q.c[2] = ac[2];     q.c[3] = cz * inv;
         TriShade& s = out.shade[i];
-        for (int v = 0; v < 3; ++v)
-            for (int k = 0; k < 3; ++k) s.n[v * 3 + k] = t.n[v][k];
-        for (int v = 0; v < 3; ++v) { s.uv[v * 2] = t.uv[v][0]; s.uv[v * 2 + 1] = t.uv[v][1]; }
+        for (int k = 0; k < 3; ++k) { s.n0[k] = t.n[0][k]; s.n1[k] = t.n[1][k]; }
+        s.n2x = t.n[2][0]; s.n2yz[0] = t.n[2][1]; s.n2yz[1] = t.n[2][2];
+        for (int k = 0; k < 2; ++k) { s.uv0[k] = t.uv[0][k]; s.uv1[k] = t.uv[1][k]; s.uv2[k] = t.uv[2][k]; }
         const rt_material& m = mats[t.material_idx];
         if (t.material_idx >= (1u << 30)) { err = "material index too large"; return RT_ERR_UNSUPPORTED; }
         s.matword = t.material_idx | (m.spec_trans > 0.5f ? 0x80000000u : 0u) | (m.shade_smooth ? 0x40000000u : 0u);
