@@ -245,21 +245,6 @@ RT_DEV void node_step(const SceneDev& sc, LaneRay& r, lds_u32* stack, uint32_t* 
     float r_hi = fminf(fminf(fmaxf(r1.x, r2.x), fmaxf(r1.y, r2.y)), fmaxf(r1.z, r2.z));
     float dl = (l_lo <= l_hi && l_hi > 0.0f) ? l_lo : INFINITY;
     float dr = (r_lo <= r_hi && r_hi > 0.0f) ? r_lo : INFINITY;
-#if defined(RT_EXP_VALU)
-    // sensitivity probe: repeat the slab arithmetic on laundered copies; results are identical
-    for (int rep = 0; rep < RT_EXP_VALU; ++rep) {
-        float4 a0 = q0, a1 = q1, a2 = q2;
-        asm volatile("" : "+v"(a0.x), "+v"(a0.y), "+v"(a0.z), "+v"(a0.w), "+v"(a1.x), "+v"(a1.y), "+v"(a1.z), "+v"(a1.w), "+v"(a2.x), "+v"(a2.y), "+v"(a2.z), "+v"(a2.w));
-        f3 xl1 = (f3{a0.x, a0.y, a0.z} - r.o) * r.inv, xl2 = (f3{a0.w, a1.x, a1.y} - r.o) * r.inv;
-        f3 xr1 = (f3{a1.z, a1.w, a2.x} - r.o) * r.inv, xr2 = (f3{a2.y, a2.z, a2.w} - r.o) * r.inv;
-        float xl_lo = fmaxf(fmaxf(fminf(xl1.x, xl2.x), fminf(xl1.y, xl2.y)), fminf(xl1.z, xl2.z));
-        float xl_hi = fminf(fminf(fmaxf(xl1.x, xl2.x), fmaxf(xl1.y, xl2.y)), fmaxf(xl1.z, xl2.z));
-        float xr_lo = fmaxf(fmaxf(fminf(xr1.x, xr2.x), fminf(xr1.y, xr2.y)), fminf(xr1.z, xr2.z));
-        float xr_hi = fminf(fminf(fmaxf(xr1.x, xr2.x), fmaxf(xr1.y, xr2.y)), fmaxf(xr1.z, xr2.z));
-        dl = fminf(dl, (xl_lo <= xl_hi && xl_hi > 0.0f) ? xl_lo : INFINITY);
-        dr = fminf(dr, (xr_lo <= xr_hi && xr_hi > 0.0f) ? xr_lo : INFINITY);
-    }
-#endif
     // intersects.comp:164-170. dl and dr are never NaN, so the child visited first has the smaller-or-equal entry distance
     // and "far child passes the strict test against the hit distance" implies "near child passes": the shader's four pushes
     // reduce to {enter near, stack far} / {enter near} / {nothing to enter: pop}.

@@ -158,6 +158,8 @@ int convert_scene(const rt_bvh_node* nodes, uint32_t n_nodes, const rt_triangle*
             stack.push_back(nd.idx);
         }
     }
+    // the traversal kernels address records with a 32-bit byte offset (64 bytes per record)
+    if (interior_order.size() >= (1u << 26)) { err = "more than 2^26 interior node records"; return RT_ERR_UNSUPPORTED; }
     out.nodes.resize(interior_order.size());
     for (size_t r = 0; r < interior_order.size(); ++r) {
         if (interior_order[r] == 0xFFFFFFFFu) { out.nodes[r] = NodePair{}; continue; }
