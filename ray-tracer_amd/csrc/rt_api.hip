@@ -295,7 +295,7 @@ int run_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t frames, uint32_t frame
         }
         {
             StageTimer tm(c, ST_SHADE, st);
-            const uint32_t per_shard = 4;
+            const uint32_t per_shard = 16;
             hipLaunchKernelGGL(k_compact_queues, dim3(kQueueShards * per_shard), dim3(kBlock), 0, st, l.stage_next.as<uint32_t>(),
                                l.shard_counts(b), queues[(b + 1) & 1], l.q_count() + b + 1, l.stage_shadow.as<uint32_t>(),
                                l.shard_counts(b) + kQueueShards, l.sq_q.as<uint32_t>(), l.sh_count() + b, c->shard_cap, per_shard);
