@@ -3,7 +3,7 @@ Renders the scene with the CPU oracle (test infrastructure) at a small resolutio
 installed, then reports the share of interior-node pops covered by K nodes chosen (a) by measured frequency,
 (b) by surface area (what a builder can know without tracing), (c) breadth-first from the root.
 
-    python tools/hot_nodes_exp.py [atrium|glass|car|interior] [width height bounces]
+    python tests/analysis/hot_nodes_exp.py [atrium|glass|car|interior] [width height bounces]
 """
 import ctypes as C
 import sys
@@ -11,7 +11,7 @@ from pathlib import Path
 
 import numpy as np
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT))
 import ray_tracer_amd as rt  # noqa: E402
 from ray_tracer_amd import scenes  # noqa: E402
