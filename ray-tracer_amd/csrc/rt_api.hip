@@ -98,7 +98,7 @@ struct rt_ctx {
     int n_cu = 256;
 
     // scene
-    DevBuf nodes, isect, shade, mats, lights, light_tris, cdf, texels, tex_table, sky, srgb;
+    DevBuf nodes, wide, isect, shade, mats, lights, light_tris, cdf, texels, tex_table, sky, srgb;
     SceneDev sd{};
     // paths: lane 0 doubles as the working set of the stage-level entry points, which run on the main stream
     Lane lanes[kMaxLanes];
@@ -460,6 +460,7 @@ extern "C" int rt_upload_scene(rt_ctx* c, const void* blob, const uint64_t sizes
         return e;
     };
     HIPCHK(c, put(c->nodes, gs.nodes.data(), gs.nodes.size() * sizeof(rtint::NodePair)));
+    HIPCHK(c, put(c->wide, gs.wide.data(), gs.wide.size() * sizeof(rtint::NodeQuad)));
     HIPCHK(c, put(c->isect, gs.isect.data(), gs.isect.size() * sizeof(rtint::TriIsect)));
     HIPCHK(c, put(c->shade, gs.shade.data(), gs.shade.size() * sizeof(rtint::TriShade)));
     HIPCHK(c, put(c->mats, mats, size_t(n_mat) * sizeof(rt_material)));
@@ -473,6 +474,9 @@ extern "C" int rt_upload_scene(rt_ctx* c, const void* blob, const uint64_t sizes
     sd.cdf = c->cdf.as<float>();
     sd.has_glass = 0;
     for (uint32_t i = 0; i < n_mat; ++i) sd.has_glass |= mats[i].spec_trans > 0.5f ? 1u : 0u;
+    sd.wide = c->wide.as<float4>();
+    sd.wide_root = gs.wide.empty() ? gs.root_ref : gs.wide_root;     // a leaf (or empty) root has no interior records at all
+    sd.n_hot_wide = gs.n_hot_wide;
     sd.root_ref = gs.root_ref; sd.n_hot = gs.n_hot; sd.n_tri = n_tri; sd.n_light = n_light; sd.n_emissive = n_emissive; sd.n_mat = n_mat;
     // The shader sizes the CDF from its 16-byte padded binding; an empty table is bound as one dummy word
     // (src/vulkan/path_tracer/descriptors.rs:85-93).

@@ -28,6 +28,21 @@ struct alignas(16) NodePair {
 };
 static_assert(sizeof(NodePair) == 64, "NodePair");
 
+// 128-byte record of the 4-wide tree the occlusion queries walk (112 bytes used): an interior node of the binary tree
+// with each interior child replaced by that child's own two children, when their boxes lie inside the child's box.
+// A ray's plane distances are monotonic in the plane coordinate, so the slab interval of a box nested in another is
+// nested in the other's interval in floating point as well: testing the grandchildren directly admits exactly the
+// boxes the two-step test admits. An occlusion query ("is any triangle hit below tmax") prunes against a constant and
+// does not depend on visiting order, so it gives the same answer on either tree.
+//   box[k] = {min.xyz, max.xyz} of entry k (all NaN for an unused entry: never hit), ref[k] as in NodePair but
+//   indexing this array.
+struct alignas(16) NodeQuad {
+    float box[4][6];
+    uint32_t ref[4];
+    uint32_t pad[4];
+};
+static_assert(sizeof(NodeQuad) == 128, "NodeQuad");
+
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kLeafMaxCount = 64;
 constexpr uint32_t kLeafMaxFirst = 1u << 25;
@@ -63,6 +78,9 @@ struct GpuScene {
     std::vector<NodePair> nodes;
     uint32_t root_ref = kRefNone;
     uint32_t n_hot = 0;          // records [0, n_hot) are the largest-area interior nodes, largest first
+    std::vector<NodeQuad> wide;  // 4-wide tree for occlusion queries (empty when the root is a leaf)
+    uint32_t wide_root = kRefNone;
+    uint32_t n_hot_wide = 0;     // wide records [0, n_hot_wide) are the largest-area ones, largest first
     std::vector<TriIsect> isect;
     std::vector<TriShade> shade;
 };

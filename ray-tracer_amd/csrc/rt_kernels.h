@@ -53,6 +53,8 @@ constexpr uint32_t kTraceBlock = RT_TRACE_BLOCK;   // workgroup size of the trav
 constexpr uint32_t kStackLds = RT_STACK_LDS;  // traversal stack entries kept in LDS per lane (4 x kTraceBlock bytes per entry per workgroup)
 constexpr uint32_t kHotLds = RT_HOT_LDS;      // node records (64 B each) every traversal workgroup keeps in LDS
 constexpr uint32_t kStackMax = 65;        // MAX_BVH_DEPTH + 1, main.comp:6 / intersects.comp:130
+constexpr uint32_t kStackMaxWide = 3 * 64 + 1;   // the 4-wide tree stacks up to three entries per level
+constexpr uint32_t kHotWide = (RT_HOT_LDS * 64u / 112u) & ~3u;   // 4-wide records (112 B used) in the same LDS bytes
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kRefNone = 0x7FFFFFFFu;
 constexpr uint32_t kNoPrim = 0xFFFFFFFFu;
@@ -68,6 +70,8 @@ struct SceneDev {
     const float* __restrict__ cdf;        // un-normalised running power
     uint32_t root_ref, n_tri, n_light, n_emissive, n_mat;
     uint32_t n_hot;                       // records [0, n_hot) of `nodes` are the largest-area nodes, largest first
+    const float4* __restrict__ wide;      // 8 x float4 per record of the 4-wide tree the occlusion queries walk
+    uint32_t wide_root, n_hot_wide;
     uint32_t has_glass;                   // any material with spec_trans > 0.5 (decides how shadow rays may terminate)
     uint32_t cdf_len_seen;                // length the light selector searches (true length unless the padded-length quirk is on)
     TexView tex;
@@ -265,6 +269,87 @@ RT_DEV void node_step(const SceneDev& sc, LaneRay& r, lds_u32* stack, uint32_t* 
     }
 }
 
+// ---- 4-wide tree (occlusion queries) -------------------------------------------------------------------
+// Record: 24 floats {min.xyz, max.xyz} x 4 entries in chunks 0-5, the four references in chunk 6. In LDS the first
+// kHotWide records are stored chunk-major like the binary ones.
+RT_DEV void load_hot_wide(const SceneDev& sc, v4f* s_hot, uint32_t n) {
+    for (uint32_t i = threadIdx.x; i < n * 8u; i += kTraceBlock) {
+        const uint32_t chunk = i & 7u;
+        if (chunk == 7u) continue;
+        float4 v = sc.wide[i];
+        s_hot[chunk * kHotWide + (i >> 3)] = v4f{v.x, v.y, v.z, v.w};
+    }
+    __syncthreads();
+}
+
+// Fetch of a 4-wide record, resident lanes from LDS and the others from global memory in one block (see fetch_node).
+RT_DEV void fetch_wide(const float4* __restrict__ wide, uint32_t cur, uint32_t n_resident, uint32_t lds_a,
+                       v4f& c0, v4f& c1, v4f& c2, v4f& c3, v4f& c4, v4f& c5, v4f& refs) {
+    const uint32_t goff = cur << 7;               // byte offset of the record: below 4 GiB (2^25 records)
+    const uint32_t lds_b = lds_a + 4u * kHotWide * 16u;
+    uint64_t saved;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "v_cmp_gt_u32 vcc, %[nres], %[cur]\n\t"
+        "s_and_b64 exec, %[sv], vcc\n\t"
+        "ds_read_b128 %[c0], %[la]\n\t"
+        "ds_read_b128 %[c1], %[la] offset:%[s1]\n\t"
+        "ds_read_b128 %[c2], %[la] offset:%[s2]\n\t"
+        "ds_read_b128 %[c3], %[la] offset:%[s3]\n\t"
+        "ds_read_b128 %[c4], %[lb]\n\t"
+        "ds_read_b128 %[c5], %[lb] offset:%[s1]\n\t"
+        "ds_read_b128 %[rf], %[lb] offset:%[s2]\n\t"
+        "s_andn2_b64 exec, %[sv], vcc\n\t"
+        "global_load_dwordx4 %[c0], %[go], %[base]\n\t"
+        "global_load_dwordx4 %[c1], %[go], %[base] offset:16\n\t"
+        "global_load_dwordx4 %[c2], %[go], %[base] offset:32\n\t"
+        "global_load_dwordx4 %[c3], %[go], %[base] offset:48\n\t"
+        "global_load_dwordx4 %[c4], %[go], %[base] offset:64\n\t"
+        "global_load_dwordx4 %[c5], %[go], %[base] offset:80\n\t"
+        "global_load_dwordx4 %[rf], %[go], %[base] offset:96\n\t"
+        "s_mov_b64 exec, %[sv]\n\t"
+        "s_waitcnt vmcnt(0) lgkmcnt(0)"
+        : [c0] "=&v"(c0), [c1] "=&v"(c1), [c2] "=&v"(c2), [c3] "=&v"(c3), [c4] "=&v"(c4), [c5] "=&v"(c5), [rf] "=&v"(refs),
+          [sv] "=&s"(saved)
+        : [nres] "s"(n_resident), [cur] "v"(cur), [la] "v"(lds_a), [lb] "v"(lds_b), [go] "v"(goff), [base] "s"(wide),
+          [s1] "n"(kHotWide * 16), [s2] "n"(kHotWide * 32), [s3] "n"(kHotWide * 48)
+        : "vcc", "memory");
+}
+
+// Entry distance of one box, +inf unless the box is hit and entered below `tmax` (intersects.comp:103-121 and the
+// strict test of intersects.comp:164-170).
+RT_DEV float box_entry(const LaneRay& r, f3 bmin, f3 bmax) {
+    f3 t1 = (bmin - r.o) * r.inv, t2 = (bmax - r.o) * r.inv;
+    float lo = fmaxf(fmaxf(fminf(t1.x, t2.x), fminf(t1.y, t2.y)), fminf(t1.z, t2.z));
+    float hi = fminf(fminf(fmaxf(t1.x, t2.x), fmaxf(t1.y, t2.y)), fmaxf(t1.z, t2.z));
+    return (lo <= hi && hi > 0.0f && lo < r.t) ? lo : INFINITY;
+}
+
+// One visit of a 4-wide record by an occlusion query: the nearest entered entry is visited next, the others are stacked
+// (their order does not affect the answer).
+RT_DEV void wide_step(const SceneDev& sc, LaneRay& r, lds_u32* stack, uint32_t* spill, const lds_v4f* hot_tab, uint32_t n_resident) {
+    static_assert(kHotWide * 48 < 65536, "chunk offsets must fit the 16-bit offset of an LDS instruction");
+    v4f c0, c1, c2, c3, c4, c5, rf;
+    fetch_wide(sc.wide, r.cur, n_resident, uint32_t(uintptr_t(hot_tab + r.cur)), c0, c1, c2, c3, c4, c5, rf);
+    const float d0 = box_entry(r, f3{c0.x, c0.y, c0.z}, f3{c0.w, c1.x, c1.y});
+    const float d1 = box_entry(r, f3{c1.z, c1.w, c2.x}, f3{c2.y, c2.z, c2.w});
+    const float d2 = box_entry(r, f3{c3.x, c3.y, c3.z}, f3{c3.w, c4.x, c4.y});
+    const float d3 = box_entry(r, f3{c4.z, c4.w, c5.x}, f3{c5.y, c5.z, c5.w});
+    const uint32_t e0 = __float_as_uint(rf.x), e1 = __float_as_uint(rf.y), e2 = __float_as_uint(rf.z), e3 = __float_as_uint(rf.w);
+    // nearest entered entry (ties: the lower index)
+    float dn = d0; uint32_t near = 0u;
+    if (d1 < dn) { dn = d1; near = 1u; }
+    if (d2 < dn) { dn = d2; near = 2u; }
+    if (d3 < dn) { dn = d3; near = 3u; }
+    const bool deep = __builtin_amdgcn_ballot_w64(r.sp + 4u >= kStackLds) != 0ull;    // wave-uniform
+    if (d0 < INFINITY && near != 0u) stack_push(stack, spill, r, e0, !deep);
+    if (d1 < INFINITY && near != 1u) stack_push(stack, spill, r, e1, !deep);
+    if (d2 < INFINITY && near != 2u) stack_push(stack, spill, r, e2, !deep);
+    if (d3 < INFINITY && near != 3u) stack_push(stack, spill, r, e3, !deep);
+    if (dn < INFINITY) r.cur = near == 0u ? e0 : (near == 1u ? e1 : (near == 2u ? e2 : e3));
+    else r.cur = stack_pop(stack, spill, r, !deep);
+}
+
 // Moeller-Trumbore exactly as hit_triangle evaluates it (intersects.comp:37-64) on the 48-byte record
 // {v0, n.x} {v1-v0, n.y} {v2-v0, n.z}. Returns false when the shader would have returned early; t may be NaN
 // (degenerate triangle), which then loses every "closer than" comparison, as there.
@@ -355,7 +440,8 @@ RT_DEV void leaf_phase(const SceneDev& sc, LaneRay& r, unsigned long long parked
 //   bool load(uint32_t i, f3& o, f3& d, float& tmax)      -- tmax is the initial "closest so far"
 // ANYHIT turns the closest-hit search into an occlusion query (stop at the first hit below tmax).
 //   void store(uint32_t i, const LaneRay& r)
-template <bool COUNT, bool ANYHIT, class Work>
+// WIDE (occlusion queries only): walk the 4-wide tree (SceneDev::wide) instead of the binary one.
+template <bool COUNT, bool ANYHIT, bool WIDE, class Work>
 RT_DEV void trace_persistent(const SceneDev& sc, const Work& work, uint32_t n, uint32_t* cursor, lds_u32* stack, lds_u8* slot_owner,
                              const HotNodes& hot, uint32_t& n_node, uint32_t& n_leaf, uint32_t& n_tri) {
     constexpr uint32_t kRefillAt = RT_REFILL_AT;     // refill once this many lanes sit idle
@@ -365,7 +451,8 @@ RT_DEV void trace_persistent(const SceneDev& sc, const Work& work, uint32_t n, u
     uint32_t kChunk = ((n / waves_total) + 63u) & ~63u;
     kChunk = kChunk < 64u ? 64u : (kChunk > RT_CHUNK ? RT_CHUNK : kChunk);
     constexpr uint32_t kLeafBatch = RT_LEAF_BATCH;   // intersect parked leaves once this many lanes wait on one
-    uint32_t spill[kStackMax - kStackLds];
+    static_assert(!WIDE || ANYHIT, "the 4-wide tree serves order-independent queries only");
+    uint32_t spill[(WIDE ? kStackMaxWide : kStackMax) - kStackLds];
     LaneRay r;
     r.cur = kDone; r.tos = kDone; r.sp = 0; r.item = 0; r.prim = kNoPrim; r.t = INFINITY; r.u = r.v = 0.0f;
     stack[0] = kDone;                                // slot 0 of this lane's stack: what a pop of the empty stack reads
@@ -414,7 +501,7 @@ RT_DEV void trace_persistent(const SceneDev& sc, const Work& work, uint32_t n, u
                 r.inv = f3{1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z};
                 r.t = tmax; r.u = 0.0f; r.v = 0.0f; r.prim = kNoPrim;
                 r.item = mine; r.sp = 0; r.tos = kDone;
-                r.cur = sc.root_ref == kRefNone ? kDone : sc.root_ref;
+                { const uint32_t root = WIDE ? sc.wide_root : sc.root_ref; r.cur = root == kRefNone ? kDone : root; }
                 live = true;
             }
             chunk_pos += n_idle < avail ? n_idle : avail;
@@ -430,7 +517,8 @@ RT_DEV void trace_persistent(const SceneDev& sc, const Work& work, uint32_t n, u
             if (uint32_t(__popcll(__builtin_amdgcn_ballot_w64(int32_t(r.cur) < 0))) >= kLeafBatch) break;
             if (at_node) {
                 if (COUNT) ++n_node;
-                node_step(sc, r, stack, spill, hot);
+                if (WIDE) wide_step(sc, r, stack, spill, hot.tab, hot.n);
+                else node_step(sc, r, stack, spill, hot);
             }
         }
         // phase B: the parked leaves
@@ -506,12 +594,13 @@ __global__ __launch_bounds__(kBlock) void k_raygen(rt_camera cam, PathDev pd, ui
 }
 
 // LDS of a traversal workgroup: the per-lane stack heads and the resident node records (filled before any ray is traced).
-#define RT_TRACE_LDS                                                                      \
-    __shared__ uint32_t s_stack[kStackLds * kTraceBlock];                                 \
-    __shared__ uint8_t s_owner[kTraceBlock];                                              \
-    __shared__ v4f s_hot[kHotLds ? kHotLds * 4 : 1];                                      \
-    const HotNodes hot{(const lds_v4f*)s_hot, sc.n_hot < kHotLds ? sc.n_hot : kHotLds};   \
-    if (kHotLds) load_hot_nodes(sc, s_hot, hot.n);
+#define RT_TRACE_LDS(use_wide)                                                                                   \
+    __shared__ uint32_t s_stack[kStackLds * kTraceBlock];                                                         \
+    __shared__ uint8_t s_owner[kTraceBlock];                                                                      \
+    __shared__ v4f s_hot[kHotLds ? kHotLds * 4 : 1];                                                              \
+    const HotNodes hot = (use_wide) ? HotNodes{(const lds_v4f*)s_hot, sc.n_hot_wide < kHotWide ? sc.n_hot_wide : kHotWide} \
+                                    : HotNodes{(const lds_v4f*)s_hot, sc.n_hot < kHotLds ? sc.n_hot : kHotLds};   \
+    if (kHotLds) { if (use_wide) load_hot_wide(sc, s_hot, hot.n); else load_hot_nodes(sc, s_hot, hot.n); }
 
 struct ExtendWork {
     PathDev pd;
@@ -571,11 +660,11 @@ template <bool COUNT>
 __global__ __launch_bounds__(kTraceBlock, RT_TRACE_WAVES_PER_EU) void k_extend(SceneDev sc, PathDev pd, const uint32_t* __restrict__ queue,
                                                    const uint32_t* __restrict__ count_ptr, uint32_t count_imm,
                                                    uint32_t* cursor, TraceStats* stats) {
-    RT_TRACE_LDS
+    RT_TRACE_LDS(false)
     const uint32_t n = count_ptr ? *count_ptr : count_imm;
     uint32_t n_node = 0, n_leaf = 0, n_tri = 0;
     ExtendWork work{pd, queue};
-    trace_persistent<COUNT, false>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, (lds_u8*)s_owner + (threadIdx.x & ~63u), hot, n_node, n_leaf, n_tri);
+    trace_persistent<COUNT, false, false>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, (lds_u8*)s_owner + (threadIdx.x & ~63u), hot, n_node, n_leaf, n_tri);
     flush_counts<COUNT>(n_node, n_leaf, n_tri, &stats->extend_node_pops, &stats->extend_leaf_pops, &stats->extend_tri_tests);
 }
 
@@ -585,11 +674,11 @@ __global__ __launch_bounds__(kTraceBlock, RT_TRACE_WAVES_PER_EU) void k_extend(S
 template <bool COUNT, bool ANYHIT>
 __global__ __launch_bounds__(kTraceBlock, RT_TRACE_WAVES_PER_EU) void k_connect(SceneDev sc, PathDev pd, ShadowQueue sq,
                                                     const uint32_t* __restrict__ count_ptr, uint32_t* cursor, TraceStats* stats) {
-    RT_TRACE_LDS
+    RT_TRACE_LDS(ANYHIT)
     const uint32_t n = *count_ptr;
     uint32_t n_node = 0, n_leaf = 0, n_tri = 0;
     ConnectWork work{sc, pd, sq};
-    trace_persistent<COUNT, ANYHIT>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, (lds_u8*)s_owner + (threadIdx.x & ~63u), hot, n_node, n_leaf, n_tri);
+    trace_persistent<COUNT, ANYHIT, ANYHIT>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, (lds_u8*)s_owner + (threadIdx.x & ~63u), hot, n_node, n_leaf, n_tri);
     flush_counts<COUNT>(n_node, n_leaf, n_tri, &stats->shadow_node_pops, &stats->shadow_leaf_pops, &stats->shadow_tri_tests);
 }
 
@@ -1005,11 +1094,12 @@ template <bool COUNT>
 __global__ __launch_bounds__(kTraceBlock, RT_TRACE_WAVES_PER_EU) void k_trace_rays(SceneDev sc, const float4* __restrict__ ro, const float4* __restrict__ rd,
                                                        uint32_t n, int shadow, float4* __restrict__ hits, uint32_t* cursor,
                                                        TraceStats* stats) {
-    RT_TRACE_LDS
+    const bool any_hit = shadow && !sc.has_glass;       // wave-uniform
+    RT_TRACE_LDS(any_hit)
     uint32_t n_node = 0, n_leaf = 0, n_tri = 0;
     RayListWork work{sc, ro, rd, hits, shadow};
-    if (shadow && !sc.has_glass) trace_persistent<COUNT, true>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, (lds_u8*)s_owner + (threadIdx.x & ~63u), hot, n_node, n_leaf, n_tri);
-    else trace_persistent<COUNT, false>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, (lds_u8*)s_owner + (threadIdx.x & ~63u), hot, n_node, n_leaf, n_tri);
+    if (any_hit) trace_persistent<COUNT, true, true>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, (lds_u8*)s_owner + (threadIdx.x & ~63u), hot, n_node, n_leaf, n_tri);
+    else trace_persistent<COUNT, false, false>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, (lds_u8*)s_owner + (threadIdx.x & ~63u), hot, n_node, n_leaf, n_tri);
     if (shadow) flush_counts<COUNT>(n_node, n_leaf, n_tri, &stats->shadow_node_pops, &stats->shadow_leaf_pops, &stats->shadow_tri_tests);
     else flush_counts<COUNT>(n_node, n_leaf, n_tri, &stats->extend_node_pops, &stats->extend_leaf_pops, &stats->extend_tri_tests);
 }

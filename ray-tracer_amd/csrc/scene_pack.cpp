@@ -184,6 +184,78 @@ int convert_scene(const rt_bvh_node* nodes, uint32_t n_nodes, const rt_triangle*
         p.ref[2] = p.ref[3] = 0;
     }
     out.root_ref = record_of[0];
+
+    // ---- 4-wide tree for occlusion queries (see NodeQuad) ----
+    {
+        auto nested = [&](uint32_t child, uint32_t parent) {       // false for NaN bounds
+            const rt_bvh_node& c = nodes[child];
+            const rt_bvh_node& p = nodes[parent];
+            for (int k = 0; k < 3; ++k)
+                if (!(c.min[k] >= p.min[k] && c.max[k] <= p.max[k])) return false;
+            return true;
+        };
+        // entries of the wide node rooted at binary interior node i
+        auto entries_of = [&](uint32_t i, uint32_t e[4]) {
+            uint32_t n = 0;
+            const uint32_t kid = nodes[i].idx;
+            for (uint32_t c = kid; c < kid + 2; ++c) {
+                const rt_bvh_node& cn = nodes[c];
+                if (cn.amt == 0 && nested(cn.idx, c) && nested(cn.idx + 1, c)) { e[n++] = cn.idx; e[n++] = cn.idx + 1; }
+                else e[n++] = c;
+            }
+            return n;
+        };
+        std::vector<uint32_t> wide_nodes{0};                        // binary nodes that head a wide record, in discovery order
+        std::vector<uint32_t> wide_of(n_nodes, 0xFFFFFFFFu);
+        wide_of[0] = 0;
+        for (size_t w = 0; w < wide_nodes.size(); ++w) {
+            uint32_t e[4];
+            const uint32_t n = entries_of(wide_nodes[w], e);
+            for (uint32_t k = 0; k < n; ++k)
+                if (nodes[e[k]].amt == 0) { wide_of[e[k]] = uint32_t(wide_nodes.size()); wide_nodes.push_back(e[k]); }
+        }
+        // order: the largest-area heads first (kept in LDS by the kernels), the rest in discovery (breadth-first) order
+        std::vector<uint32_t> order(wide_nodes.size());
+        for (size_t k = 0; k < order.size(); ++k) order[k] = uint32_t(k);
+        auto area = [&](uint32_t w) {
+            const rt_bvh_node& b = nodes[wide_nodes[w]];
+            float ex = b.max[0] - b.min[0], ey = b.max[1] - b.min[1], ez = b.max[2] - b.min[2];
+            float a = ex * ey + ey * ez + ez * ex;
+            return (a == a && ex >= 0.0f && ey >= 0.0f && ez >= 0.0f) ? a : -1.0f;
+        };
+        const size_t n_hot = std::min<size_t>(hot_slots, order.size());
+        std::partial_sort(order.begin(), order.begin() + n_hot, order.end(), [&](uint32_t a, uint32_t b) {
+            float aa = area(a), ab = area(b);
+            return aa != ab ? aa > ab : a < b;
+        });
+        std::sort(order.begin() + n_hot, order.end());
+        std::vector<uint32_t> slot_of(order.size());
+        for (size_t s = 0; s < order.size(); ++s) slot_of[order[s]] = uint32_t(s);
+        if (order.size() >= (1u << 25)) { err = "more than 2^25 wide node records"; return RT_ERR_UNSUPPORTED; }
+        out.wide.assign(order.size(), NodeQuad{});
+        const float nan = std::nanf("");
+        for (size_t s = 0; s < order.size(); ++s) {
+            NodeQuad& q = out.wide[s];
+            uint32_t e[4];
+            const uint32_t n = entries_of(wide_nodes[order[s]], e);
+            for (uint32_t k = 0; k < 4; ++k) {
+                if (k >= n) {
+                    for (int j = 0; j < 6; ++j) q.box[k][j] = nan;
+                    q.ref[k] = kRefNone;
+                    continue;
+                }
+                const rt_bvh_node& b = nodes[e[k]];
+                for (int j = 0; j < 3; ++j) { q.box[k][j] = b.min[j]; q.box[k][3 + j] = b.max[j]; }
+                if (b.amt != 0) {
+                    if (!leaf_ref(b, q.ref[k])) { err = "leaf range invalid, larger than 64 triangles, or beyond 2^25 triangles"; return RT_ERR_UNSUPPORTED; }
+                } else {
+                    q.ref[k] = slot_of[wide_of[e[k]]];
+                }
+            }
+        }
+        out.wide_root = slot_of[0];
+        out.n_hot_wide = uint32_t(n_hot);
+    }
     return RT_OK;
 }
 
