@@ -48,9 +48,10 @@ def algorithmic_bytes_extend(rays, node_pops, tri_tests):
     return rays * (32 + 16 + 32) + node_pops * 64 + tri_tests * 48
 
 
-def algorithmic_bytes_connect(rays, node_pops, tri_tests):
-    # per shadow ray: 32 B ray + 16 B queued contribution in, 4 B result, 32 B root node
-    return rays * (32 + 16 + 4 + 32) + node_pops * 64 + tri_tests * 48
+def algorithmic_bytes_connect(rays, node_pops, tri_tests, wide):
+    # per shadow ray: 32 B ray + 16 B queued contribution in, 4 B result, 32 B root node; per node visit two 32-B child boxes,
+    # or four 24-B boxes + four references (112 B) when the occlusion queries walk the 4-wide tree (scenes without glass)
+    return rays * (32 + 16 + 4 + 32) + node_pops * (112 if wide else 64) + tri_tests * 48
 
 
 def main():
@@ -196,7 +197,8 @@ def main():
         tm = rtm.last_timer_perf()
         rtm.destroy()
         b_ext = algorithmic_bytes_extend(c["extend_rays"], c["extend_node_pops"], c["extend_tri_tests"])
-        b_con = algorithmic_bytes_connect(c["shadow_rays"], c["shadow_node_pops"], c["shadow_tri_tests"])
+        wide = not bool((scene.materials["spec_trans"] > 0.5).any())
+        b_con = algorithmic_bytes_connect(c["shadow_rays"], c["shadow_node_pops"], c["shadow_tri_tests"], wide)
         ext_s = tm["extend_ms"] / 1e3
         achieved = b_ext / ext_s / 1e9 if ext_s > 0 else 0.0
         # HBM-side bytes per launch of the same kernel, from the committed rocprofv3 counter passes of this exact workload
@@ -231,6 +233,7 @@ def main():
         result["kernel_ms_per_sample"]["total"] = tm["total_ms"] / k
         result["connect"] = {"achieved_GBs": b_con / con_s / 1e9 if con_s > 0 else 0.0,
                              "mrays_per_s": c["shadow_rays"] / con_s / 1e6 if con_s > 0 else 0.0,
+                             "tree": "4-wide (any-hit)" if wide else "binary (closest hit, glass rule)",
                              "node_pops_per_ray": c["shadow_node_pops"] / max(1, c["shadow_rays"]),
                              "tri_tests_per_ray": c["shadow_tri_tests"] / max(1, c["shadow_rays"])}
 
