@@ -233,6 +233,41 @@ def test_lds_resident_node_prefix_does_not_change_results(rt, oracle, scene_cach
         assert np.array_equal(g["u"], h["u"]) and np.array_equal(g["v"], h["v"])
 
 
+def test_occlusion_tree_collapse_respects_boxes_that_are_not_nested(rt, oracle):
+    """Occlusion queries walk a 4-wide tree collapsed from the binary one, which is exact only where a child's box lies
+    inside its parent's. A hand-made tree whose grandchild box sticks out of its parent's box must not be collapsed there:
+    a ray through the protruding part misses the parent's box, so the reference never tests that triangle."""
+    from ray_tracer_amd.scene import Scene, default_material, look_at_camera, make_triangles
+    verts = np.array([
+        [[2.2, 0.1, 0.5], [2.9, 0.1, 0.5], [2.5, 0.9, 0.5]],     # in node 3, outside node 1's box
+        [[0.1, 0.1, 0.5], [0.9, 0.1, 0.5], [0.5, 0.9, 0.5]],     # in node 4, inside
+        [[5.1, 0.1, 0.5], [5.9, 0.1, 0.5], [5.5, 0.9, 0.5]],     # node 2
+    ], np.float32)
+    sc = Scene(triangles=make_triangles(verts, None, None, np.zeros(3, np.uint32)), materials=default_material(1),
+               camera=look_at_camera(8, 8, (0, 0, 4), (0, 0, 0)))
+    nodes = np.zeros(5, dtype=rt.api.BVH_NODE)
+    def put(i, lo, hi, idx, amt):
+        nodes[i]["min"], nodes[i]["max"], nodes[i]["idx"], nodes[i]["amt"] = lo, hi, idx, amt
+    put(0, (0, 0, 0), (6, 1, 1), 1, 0)
+    put(1, (0, 0, 0), (1, 1, 1), 3, 0)          # too small for its left child
+    put(2, (5, 0, 0), (6, 1, 1), 2, 1)
+    put(3, (0, 0, 0), (3, 1, 1), 0, 1)
+    put(4, (0, 0, 0), (1, 1, 1), 1, 1)
+    sc.bvh = nodes
+    sc.build_lights()
+    r = rt.HipRenderer.create(sc, max_bounces=2)
+    o = oracle.OracleScene(sc)
+    ro = np.array([[2.5, 0.4, 3.0], [0.5, 0.4, 3.0], [5.5, 0.4, 3.0], [3.5, 0.4, 3.0]], np.float32)
+    rd = np.tile(np.array([[0, 0, -1]], np.float32), (4, 1))
+    tmax = np.full(4, 10.0, np.float32)
+    want = o.trace_shadow(ro, rd, tmax)
+    assert list(want) == [1, 0, 0, 1]                          # the protruding triangle is never reached
+    assert np.array_equal(r.trace_shadow(ro, rd, tmax), want)
+    g, h = r.trace_closest(ro, rd), o.trace_closest(ro, rd)[0]
+    assert np.array_equal(g["prim"], h["prim"]) and np.array_equal(g["t"], h["t"])
+    r.destroy()
+
+
 def test_extend_empty_scene_and_ragged_sizes(rt):
     from ray_tracer_amd.scene import Scene, default_material, look_at_camera
     cam = look_at_camera(37, 23, (0, 0, 3), (0, 0, 0))
