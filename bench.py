@@ -205,7 +205,7 @@ def main():
         # (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; tools/profile_gpu.sh). Counters cannot be read from inside this process.
         traffic = None
         prof = {}
-        tfile = ROOT / "profiles" / "r1_v4_traffic.json"
+        tfile = ROOT / "profiles" / "r1_v5_traffic.json"
         default_cfg = (args.scene == "atrium" and args.scale == 1.0 and (args.width, args.height, args.bounces) == (1920, 1080, 8)
                        and args.frames_per_pass == 0 and args.bvh == "spatial")
         if default_cfg and tfile.exists():
@@ -214,7 +214,7 @@ def main():
         result["roofline"] = {
             "kernel": "k_extend", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "traffic_note": "bytes per launch beyond L2 (Infinity Cache hits included), profiles/r1_v4_traffic.json; algorithmic bytes "
+            "traffic_note": "bytes per launch beyond L2 (Infinity Cache hits included), profiles/r1_v5_traffic.json; algorithmic bytes "
                             "charge every node visit to HBM, so achieved exceeds the HBM peak: about 60 % of the node visits are "
                             "served from LDS-resident records and most of the rest from L1/L2",
             "measured_in": "a separate context with per-kernel events (single stream: kernels run alone, as in the rocprofv3 "
