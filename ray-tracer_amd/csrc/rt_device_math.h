@@ -86,14 +86,17 @@ struct TexView {
     uint32_t sky_w, sky_h;
     const float* __restrict__ srgb;        // 256-entry decode table
 };
-RT_DEV f4 decode_texel(const TexView& tv, uint32_t w) {
+// `srgb_lds`, when not null, is a copy of the decode table in LDS: three dependent table reads per texel, twelve per
+// bilinear fetch, then stay off the vector-memory pipeline.
+RT_DEV f4 decode_texel(const TexView& tv, const lds_f32* srgb_lds, uint32_t w) {
+    if (srgb_lds) return {srgb_lds[w & 255u], srgb_lds[(w >> 8) & 255u], srgb_lds[(w >> 16) & 255u], float(w >> 24) / 255.0f};
     return {tv.srgb[w & 255u], tv.srgb[(w >> 8) & 255u], tv.srgb[(w >> 16) & 255u], float(w >> 24) / 255.0f};
 }
 RT_DEV f4 lerp4(f4 a, f4 b, float f) { return {mixf(a.x, b.x, f), mixf(a.y, b.y, f), mixf(a.z, b.z, f), mixf(a.w, b.w, f)}; }
 RT_DEV int wrapi(int i, int n) { int m = i % n; return m < 0 ? m + n : m; }
 RT_DEV int clampi(int i, int n) { return i < 0 ? 0 : (i >= n ? n - 1 : i); }
 
-RT_DEV f4 sample_2d(const TexView& tv, uint32_t tex, float u, float v) {  // REPEAT addressing
+RT_DEV f4 sample_2d(const TexView& tv, uint32_t tex, float u, float v, const lds_f32* srgb_lds = nullptr) {  // REPEAT addressing
     if (tex >= tv.n_tex) return {1.0f, 1.0f, 1.0f, 1.0f};
     uint4 e = tv.table[tex];
     int W = int(e.y), H = int(e.z);
@@ -107,13 +110,13 @@ RT_DEV f4 sample_2d(const TexView& tv, uint32_t tex, float u, float v) {  // REP
     int x0 = wrapi(int(x0f), W), x1 = wrapi(int(x0f) + 1, W);
     int y0 = wrapi(int(y0f), H), y1 = wrapi(int(y0f) + 1, H);
     const uint32_t* base = tv.texels + e.x;
-    f4 t00 = decode_texel(tv, base[y0 * W + x0]), t10 = decode_texel(tv, base[y0 * W + x1]);
-    f4 t01 = decode_texel(tv, base[y1 * W + x0]), t11 = decode_texel(tv, base[y1 * W + x1]);
+    f4 t00 = decode_texel(tv, srgb_lds, base[y0 * W + x0]), t10 = decode_texel(tv, srgb_lds, base[y0 * W + x1]);
+    f4 t01 = decode_texel(tv, srgb_lds, base[y1 * W + x0]), t11 = decode_texel(tv, srgb_lds, base[y1 * W + x1]);
     return lerp4(lerp4(t00, t10, fx), lerp4(t01, t11, fx), fy);
 }
 
 // Cube fetch (main.comp:82-84): major axis picks the face (ties: z, then y, then x); clamp to the face edge.
-RT_DEV f4 sample_cube(const TexView& tv, f3 d) {
+RT_DEV f4 sample_cube(const TexView& tv, f3 d, const lds_f32* srgb_lds = nullptr) {
     float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
     int face;
     float sc, tc, ma;
@@ -130,8 +133,8 @@ RT_DEV f4 sample_cube(const TexView& tv, f3 d) {
     int x0 = clampi(int(x0f), W), x1 = clampi(int(x0f) + 1, W);
     int y0 = clampi(int(y0f), H), y1 = clampi(int(y0f) + 1, H);
     const uint32_t* base = tv.sky + size_t(face) * W * H;
-    f4 t00 = decode_texel(tv, base[y0 * W + x0]), t10 = decode_texel(tv, base[y0 * W + x1]);
-    f4 t01 = decode_texel(tv, base[y1 * W + x0]), t11 = decode_texel(tv, base[y1 * W + x1]);
+    f4 t00 = decode_texel(tv, srgb_lds, base[y0 * W + x0]), t10 = decode_texel(tv, srgb_lds, base[y0 * W + x1]);
+    f4 t01 = decode_texel(tv, srgb_lds, base[y1 * W + x0]), t11 = decode_texel(tv, srgb_lds, base[y1 * W + x1]);
     return lerp4(lerp4(t00, t10, fx), lerp4(t01, t11, fx), fy);
 }
 

@@ -711,6 +711,10 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_WAVES) void k_shade(SceneDev sc, P
     __shared__ v4f s_mats[LDS_TABLES ? kLdsMats * 6 : 1];
     __shared__ v4f s_lt[LDS_TABLES ? kLdsLights * 4 : 1];
     __shared__ float s_cdf[LDS_TABLES ? kLdsLights : 1];
+    __shared__ float s_srgb[256];
+    s_srgb[threadIdx.x & 255u] = sc.tex.srgb[threadIdx.x & 255u];
+    const lds_f32* l_srgb = (const lds_f32*)s_srgb;
+    if (!LDS_TABLES) __syncthreads();
     if (LDS_TABLES) {
         for (uint32_t k = threadIdx.x; k < sc.n_mat * 6; k += kBlock) { float4 v = sc.mats[k]; s_mats[k] = v4f{v.x, v.y, v.z, v.w}; }
         for (uint32_t k = threadIdx.x; k < sc.n_emissive * 4; k += kBlock) { float4 v = sc.light_tris[k]; s_lt[k] = v4f{v.x, v.y, v.z, v.w}; }
@@ -738,7 +742,7 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_WAVES) void k_shade(SceneDev sc, P
             uint32_t seed = __float_as_uint(R4.w);
             uint32_t prim = __float_as_uint(h4.w);
             if (prim == kNoPrim) {
-                f4 bg = sample_cube(sc.tex, rd);                          // main.comp:137-140
+                f4 bg = sample_cube(sc.tex, rd, l_srgb);                          // main.comp:137-140
                 rad = rad + f3{bg.x, bg.y, bg.z} * thr;
             } else {
                 const float t = h4.x, u = h4.y, v = h4.z, w = 1.0f - h4.y - h4.z;
@@ -779,11 +783,11 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_WAVES) void k_shade(SceneDev sc, P
                 else
                     normal = f3{A.w, B.w, C.w};
                 // texture modulation, main.comp:141-159
-                if (m.base_tex != 0xFFFFFFFFu) { f4 c = sample_2d(sc.tex, m.base_tex, uvx, uvy); m.base = m.base * f3{c.x, c.y, c.z}; }
-                if (m.mr_tex != 0xFFFFFFFFu) { f4 c = sample_2d(sc.tex, m.mr_tex, uvx, uvy); m.metallic *= c.z; m.roughness *= c.y; }
-                if (m.emission_tex != 0xFFFFFFFFu) { f4 c = sample_2d(sc.tex, m.emission_tex, uvx, uvy); m.emission = m.emission * f3{c.x, c.y, c.z}; }
+                if (m.base_tex != 0xFFFFFFFFu) { f4 c = sample_2d(sc.tex, m.base_tex, uvx, uvy, l_srgb); m.base = m.base * f3{c.x, c.y, c.z}; }
+                if (m.mr_tex != 0xFFFFFFFFu) { f4 c = sample_2d(sc.tex, m.mr_tex, uvx, uvy, l_srgb); m.metallic *= c.z; m.roughness *= c.y; }
+                if (m.emission_tex != 0xFFFFFFFFu) { f4 c = sample_2d(sc.tex, m.emission_tex, uvx, uvy, l_srgb); m.emission = m.emission * f3{c.x, c.y, c.z}; }
                 if (m.normal_tex != 0xFFFFFFFFu) {
-                    f4 c = sample_2d(sc.tex, m.normal_tex, uvx, uvy);
+                    f4 c = sample_2d(sc.tex, m.normal_tex, uvx, uvy, l_srgb);
                     f3 tn = f3{c.x, c.y, c.z} * 2.0f - mk3(1.0f);
                     float d1x = s3.x - s2.z, d1y = s3.y - s2.w, d2x = s3.z - s2.z, d2y = s3.w - s2.w;  // intersects.comp:82-89
                     float f = 1.0f / (d1x * d2y - d2x * d1y);
