@@ -212,12 +212,31 @@ int resolve_timings(rt_ctx* c) {
     return RT_OK;
 }
 
+int alloc_paths_for(rt_ctx* c, uint32_t fpp_limit);
+
+// Path buffers for the configured number of frames per pass. The automatic size (a few GiB per lane, chosen for the
+// 288 GB of an MI355X) is halved until the allocation succeeds, so the library also runs beside other users of the device.
 int alloc_paths(rt_ctx* c) {
+    const bool automatic = c->fpp_cfg == 0 && !(c->flags & RT_REF_RGBA8_ACCUM);
+    for (uint32_t limit = 64;; limit /= 2) {
+        int rc = alloc_paths_for(c, limit);
+        if (rc != RT_ERR_OOM || !automatic || limit <= 1 || c->fpp <= 1) return rc;
+        for (uint32_t i = 0; i < c->n_lanes; ++i) {          // give back what the failed attempt got
+            Lane& l = c->lanes[i];
+            for (DevBuf* b : {&l.ray_o, &l.ray_d, &l.hit, &l.thr, &l.rad, &l.q0, &l.q1, &l.sq_o, &l.sq_d, &l.sq_c, &l.sq_q, &l.stage_next, &l.stage_shadow})
+                b->release();
+        }
+        (void)hipGetLastError();
+        limit = std::min(limit, c->fpp);
+    }
+}
+
+int alloc_paths_for(rt_ctx* c, uint32_t fpp_limit) {
     uint32_t fpp = c->fpp_cfg;
     if (c->flags & RT_REF_RGBA8_ACCUM) fpp = 1;
     if (fpp == 0) {
         const uint64_t target = 64ull << 20;  // ~64 M paths per lane keep every CU fed through the late, sparse bounces (~10 GiB of path state and queues each)
-        fpp = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(64, target / std::max<uint32_t>(1, c->npix))));
+        fpp = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(fpp_limit, target / std::max<uint32_t>(1, c->npix))));
     }
     c->fpp = fpp;
     uint64_t slots = uint64_t(fpp) * c->npix;
