@@ -124,11 +124,14 @@ RT_DEV uint32_t wave_sum(uint32_t v) {
 // strictly below the current hit distance, triangles of a leaf in storage order with a strict "closer" test, so the
 // first triangle tested wins an exact tie. Only the scheduling across the 64 lanes differs from a per-thread loop:
 //
-//   * persistent wavefronts pull rays from a device-side cursor and refill lanes whose ray has finished, so a wave
-//     is not held hostage by its slowest ray;
-//   * "while-while": all lanes first walk interior nodes until every live lane is parked on a leaf (or done), then
-//     the parked leaves are intersected together. Box tests and triangle tests are therefore each executed with
-//     most lanes active instead of being serialised inside every iteration.
+//   * persistent wavefronts own chunks of consecutive work items (the tail of each list is handed out through a
+//     device-side cursor) and refill lanes whose ray has finished, so a wave is not held hostage by its slowest ray;
+//   * lanes walk interior nodes until enough of them are parked on a leaf (or none has a node left), then the parked
+//     leaves are intersected together, closest-hit queries with the whole wavefront sharing the triangles. Box tests
+//     and triangle tests are therefore each executed with most lanes active instead of being serialised inside every
+//     iteration;
+//   * the records of the largest nodes are read from a copy in LDS.
+// Occlusion queries (any hit below a fixed distance) do not depend on visiting order and walk a 4-wide tree instead.
 //
 // The traversal stack keeps its top entry in a register, the next kStackLds - 1 per lane in LDS (entry-major, so lanes
 // never conflict on a bank) and the rest, up to the reference's bound of 65, in per-lane scratch.
