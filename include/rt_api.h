@@ -90,6 +90,42 @@ typedef struct rt_hit {
     uint32_t prim;
 } rt_hit;
 
+/* One path on arrival at a vertex, as the extend stage leaves it: the ray of this bounce, its closest hit, and what the
+ * path carries (main.comp:122-134,188-209). Input record of rt_shade_vertices. 64 bytes. */
+typedef struct rt_shade_vertex {
+    float    ray_o[3];
+    float    prev_pdf;        /* pdf of the BSDF sample that produced the ray (bsdfPdf, main.comp:197); 0 at bounce 0 */
+    float    ray_d[3];
+    uint32_t seed;            /* RNG state (random.comp:6-12) before this vertex's draws                            */
+    float    throughput[3];
+    uint32_t reserved;
+    rt_hit   hit;             /* prim = 0xFFFFFFFF: the ray left the scene                                          */
+} rt_shade_vertex;
+
+/* What the shade stage does with one vertex (main.comp:137-209). 144 bytes. */
+typedef struct rt_shade_result {
+    float    emitted[3];      /* radiance added at the vertex itself: sky on a miss, MIS-weighted emission on a hit  */
+    uint32_t seed;            /* RNG state after this vertex's draws                                                */
+    float    throughput[3];   /* after absorption, the BSDF sample and Russian roulette                            */
+    float    pdf;             /* pdf of the BSDF sample (carried to the next vertex)                                */
+    float    next_o[3];
+    uint32_t alive;           /* 1: the path continues along next_o / next_d                                        */
+    float    next_d[3];
+    uint32_t has_shadow;      /* 1: a light sample was queued for the connect stage                                 */
+    float    shadow_o[3];
+    float    shadow_tmax;     /* distance to the sampled point minus 0.001 (disney.comp:699)                        */
+    float    shadow_d[3];
+    int32_t  light_index;     /* int(rand * numOfLights), disney.comp:673; -1 when the scene has no light           */
+    float    shadow_contrib[3]; /* weight * f * Le / pdf * throughput: what connect adds if nothing opaque intervenes */
+    int32_t  lobe;            /* lobe DisneySample chose: 0 diffuse, 1 reflection, 2 refraction, 3 clearcoat; -1 none */
+    int32_t  light_tri;       /* entry of the emissive-triangle table SampleMeshCDF chose; -1 for point lights / none */
+    float    light_pdf;       /* pdf of the light sample (selection x area measure converted to solid angle)        */
+    float    bsdf_pdf_light;  /* DisneyEval's pdf for the light direction (the other side of the MIS weight)        */
+    float    roughness;       /* roughness the BSDF used: after the metallic-roughness texture and the 0.001 clamp   */
+    float    medium_throughput[3]; /* throughput after the absorption step (main.comp:182-184), before the BSDF sample */
+    uint32_t reserved;
+} rt_shade_result;
+
 typedef struct rt_bvh_params {
     float    traversal_cost;  /* 1.0 */
     float    intersect_cost;  /* 1.0 */
@@ -168,7 +204,7 @@ int rt_upload_scene(rt_ctx* ctx, const void* blob, const uint64_t sizes[6],
 
 /* Texture array + cube map upload (path_tracer/mod.rs:99-137). All images are RGBA8 holding sRGB-encoded values,
  * sampled bilinearly with one mip level; 2-D textures REPEAT, the cube clamps to the face edge
- * (src/vulkan/core/image.rs:307-318, sampler.rs:10-34). skybox == NULL keeps/installs the 1x1 white cube
+ * (src/vulkan/core/image.rs:307-318, sampler.rs:10-34). skybox == NULL installs the 1x1 white cube, replacing any cube map uploaded earlier
  * (src/scene/mod.rs:49-65). */
 int rt_upload_textures(rt_ctx* ctx, const rt_texture* textures, uint32_t n_textures, const rt_texture* skybox);
 
@@ -239,6 +275,13 @@ int rt_sample_bsdf(rt_ctx* ctx, uint32_t n, const rt_material* mats, const float
                    const float* r1r2, float* out_L, float* out_f, float* out_pdf);
 /* Bilinear sRGB fetch of texture `tex` (or the cube map when tex == 0xFFFFFFFF, with uvw = direction). uvw: n x 3. */
 int rt_sample_texture(rt_ctx* ctx, uint32_t tex, uint32_t n, const float* uvw, float* rgba);
+
+/* shade stage = everything ray_color does at one path vertex between the two traversals (main.comp:137-209;
+ * DirectLight disney.comp:623-720 up to, not including, its shadow test; DisneySample disney.comp:476-558): the kernel
+ * rt_render launches, run on n caller-supplied vertices as vertex number `bounce` of their paths. n may not exceed
+ * width * height * frames_per_pass of the context, and bounce must be below max_bounces. At the last bounce
+ * (bounce + 1 == max_bounces) the stage draws no BSDF sample: nothing it could produce is ever looked at. */
+int rt_shade_vertices(rt_ctx* ctx, uint32_t n, uint32_t bounce, const rt_shade_vertex* vertices, rt_shade_result* results);
 
 /* Per-pixel radiance of ONE sample (frame index `frame`), before firefly clamp and accumulation:
  * ray_color (main.comp:122-213). Does not touch the accumulator. rgb: width*height x 3 floats. */

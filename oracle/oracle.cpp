@@ -28,7 +28,7 @@
 #include <thread>
 #include <vector>
 
-#include "../include/rt_types.h"
+#include "../include/rt_api.h"   // declarations only (wire records and the stage-probe records); nothing is linked
 
 namespace {
 
@@ -316,6 +316,24 @@ vec4 sample_cube(const Scene& sc, vec3 d) {
     return lerp4(top, bot, fy);
 }
 
+// ---------------------------------------------------------------- libm sensitivity probe
+// GLSL leaves sin/cos/log/exp/pow to the implementation (a few ulp); two correct implementations of the shader therefore
+// differ wherever a formula amplifies those last bits (a GGX peak at roughness 0.001, a cosine sample at grazing angle).
+// To tell such vertices from real defects the tests re-evaluate a vertex with these five functions nudged by a few ulp and
+// take the spread as that vertex's conditioning. With all biases 0 (the default, and the only setting any render uses)
+// the wrappers return the library values untouched.
+static int g_bias_sin = 0, g_bias_cos = 0, g_bias_other = 0;
+inline float nudge(float y, int k) {
+    for (; k > 0; --k) y = nextafterf(y, INFINITY);
+    for (; k < 0; ++k) y = nextafterf(y, -INFINITY);
+    return y;
+}
+inline float m_sin(float x) { return nudge(sinf(x), g_bias_sin); }
+inline float m_cos(float x) { return nudge(cosf(x), g_bias_cos); }
+inline float m_log(float x) { return nudge(logf(x), g_bias_other); }
+inline float m_exp(float x) { return nudge(expf(x), g_bias_other); }
+inline float m_pow(float x, float y) { return nudge(powf(x, y), g_bias_other); }
+
 // ---------------------------------------------------------------- Disney BSDF (disney.comp)
 inline float Luminance(vec3 c) { return 0.212671f * c.x + 0.715160f * c.y + 0.072169f * c.z; }  // :30-33
 
@@ -323,16 +341,16 @@ inline float GTR1(float NDotH, float a) {  // :37-44
     if (a >= 1.0f) return INV_PI;
     float a2 = a * a;
     float t = 1.0f + (a2 - 1.0f) * NDotH * NDotH;
-    return (a2 - 1.0f) / (PI * logf(a2) * t);
+    return (a2 - 1.0f) / (PI * m_log(a2) * t);
 }
 inline vec3 SampleGTR1(float rgh, float r1, float r2) {  // :46-59
     (void)r2;
     float a = fmaxf(0.001f, rgh);
     float a2 = a * a;
     float phi = r1 * TWO_PI;
-    float cosTheta = sqrtf((1.0f - powf(a2, 1.0f - r1)) / (1.0f - a2));
+    float cosTheta = sqrtf((1.0f - m_pow(a2, 1.0f - r1)) / (1.0f - a2));
     float sinTheta = clampf(sqrtf(1.0f - (cosTheta * cosTheta)), 0.0f, 1.0f);
-    float sinPhi = sinf(phi), cosPhi = cosf(phi);
+    float sinPhi = m_sin(phi), cosPhi = m_cos(phi);
     return {sinTheta * cosPhi, sinTheta * sinPhi, cosTheta};
 }
 inline float GTR2(float NDotH, float a) {  // :61-66
@@ -347,8 +365,8 @@ inline vec3 SampleGGXVNDF(vec3 Vv, float rgh, float r1, float r2) {  // :82-100
     vec3 T2 = cross(Vh, T1);
     float r = sqrtf(r1);
     float phi = 2.0f * PI * r2;
-    float t1 = r * cosf(phi);
-    float t2 = r * sinf(phi);
+    float t1 = r * m_cos(phi);
+    float t2 = r * m_sin(phi);
     float s = 0.5f * (1.0f + Vh.z);
     t2 = (1.0f - s) * sqrtf(1.0f - t1 * t1) + s * t2;
     vec3 Nh = t1 * T1 + t2 * T2 + sqrtf(fmaxf(0.0f, 1.0f - t1 * t1 - t2 * t2)) * Vh;
@@ -376,8 +394,8 @@ inline vec3 CosineSampleHemisphere(float r1, float r2) {  // :159-168
     float r = sqrtf(r1);
     float phi = TWO_PI * r2;
     vec3 d;
-    d.x = r * cosf(phi);
-    d.y = r * sinf(phi);
+    d.x = r * m_cos(phi);
+    d.y = r * m_sin(phi);
     d.z = sqrtf(fmaxf(0.0f, 1.0f - d.x * d.x - d.y * d.y));
     return d;
 }
@@ -439,7 +457,7 @@ vec3 EvalSpecRefraction(const rt_material& m, float eta, vec3 Vv, vec3 L, vec3 H
     float jacobian = fabsf(dot(L, H)) / denom;
     pdf = G1 * fmaxf(0.0f, dot(Vv, H)) * D * jacobian / Vv.z;
     vec3 bc = base(m);
-    vec3 specColor{powf(bc.x, 0.5f), powf(bc.y, 0.5f), powf(bc.z, 0.5f)};
+    vec3 specColor{m_pow(bc.x, 0.5f), m_pow(bc.y, 0.5f), m_pow(bc.z, 0.5f)};
     return specColor * (1.0f - m.metallic) * m.spec_trans * (1.0f - F) * D * G2 * fabsf(dot(Vv, H)) * fabsf(dot(L, H)) *
            eta * eta / (denom * fabsf(L.z) * fabsf(Vv.z));
 }
@@ -475,7 +493,7 @@ inline void GetLobeProbabilities(const rt_material& m, vec3 specCol, float appro
 }
 
 // DisneySample, disney.comp:476-558, with the two random numbers passed in.
-vec3 DisneySample(const rt_material& m, float eta, vec3 Vw, vec3 N, float r1, float r2, vec3& L, float& pdf) {
+vec3 DisneySample(const rt_material& m, float eta, vec3 Vw, vec3 N, float r1, float r2, vec3& L, float& pdf, int* lobe = nullptr) {
     pdf = 0.0f;
     vec3 f = V(0.0f);
     vec3 T, B;
@@ -489,6 +507,7 @@ vec3 DisneySample(const rt_material& m, float eta, vec3 Vw, vec3 N, float r1, fl
     float cdf0 = diffuseWt;
     float cdf1 = cdf0 + specReflectWt;
     float cdf2 = cdf1 + specRefractWt;
+    if (lobe) *lobe = r1 < cdf0 ? 0 : (r1 < cdf1 ? 1 : (r1 < cdf2 ? 2 : 3));
     if (r1 < cdf0) {
         r1 /= cdf0;
         L = CosineSampleHemisphere(r1, r2);
@@ -604,142 +623,215 @@ float MeshLightPdf(const Scene& sc, const Hit& hit, vec3 rayDir, int numOfLights
 
 struct LightSample { vec3 normal{}, emission{}, direction{}; float dist = 0, pdf = 0; };
 
-vec3 DirectLight(const Scene& sc, uint32_t flags, const Ray& r, const Hit& rec, uint32_t& seed, int numOfLights, Counters* cn) {
-    vec3 Li = V(0.0f);
+// Everything DirectLight (disney.comp:623-720) does except the visibility test: which light, which point on it, the
+// shadow ray, and the contribution the sample makes if it turns out to be unoccluded. The shader traces the shadow ray
+// first and evaluates the BSDF afterwards; no random number is drawn in between, so the order does not show.
+struct LightPick {
+    int light_index = -1;      // light_rand * numOfLights, -1 when the scene has no lights (no number drawn)
+    int tri = -1;              // entry of the emissive-triangle table (mesh lights only)
+    bool traced = false;       // the light faces the surface: the shader traces a shadow ray (disney.comp:697)
+    vec3 origin{}, direction{};
+    float dist = 0.0f;         // distance to the sampled point; occluded means a blocker nearer than dist - EPS
+    float light_pdf = 0.0f, bsdf_pdf = 0.0f;
+    vec3 Li{};                 // weight * f * Le / pdf if unoccluded (zero when the BSDF pdf is not positive)
+};
+
+LightPick SampleDirect(const Scene& sc, uint32_t flags, const Ray& r, const Hit& rec, uint32_t& seed, int numOfLights) {
+    LightPick lp;
     vec3 surfacePos = rec.pos + rec.normal * EPS;
     int num_point = int(sc.lights.size());
     int num_mesh = int(sc.emissive.size());
     bool isDelta = false;
-    if (numOfLights > 0) {
-        LightSample ls;
-        float light_rand = pcg(seed);
-        int light_index = int(light_rand * float(numOfLights));
-        if (light_index < num_point) {
-            const rt_light& lt = sc.lights[size_t(light_index)];
-            isDelta = (int(lt.type) == 0);
-            ls.direction = v3(lt.position) - surfacePos;  // SamplePointLight :216-225
-            ls.dist = length(ls.direction);
-            float distSq = ls.dist * ls.dist;
-            ls.direction /= ls.dist;
-            ls.normal = -ls.direction;
-            ls.emission = v3(lt.emission);
-            ls.pdf = 1.0f / distSq;
-            ls.pdf *= float(numOfLights);
-        } else {
-            float cdf_rand = pcg(seed);
-            float triProb;
-            int tri_idx = SampleMeshCDF(sc, flags, cdf_rand, triProb);
-            float selectProb = (float(num_mesh) / float(numOfLights)) * triProb;
-            // reading past the emissive table (possible only with the padded-CDF quirk) yields zeros
-            rt_emissive_tri et{0, 0, 0.0f, 0.0f};
-            if (size_t(tri_idx) < sc.emissive.size()) et = sc.emissive[size_t(tri_idx)];
-            const rt_triangle& tr = sc.tris[et.tri_index];  // SampleMeshLight :230-264
-            float r1 = pcg(seed);
-            float r2 = pcg(seed);
-            float sq = sqrtf(r1);
-            float u = 1.0f - sq;
-            float v = r2 * sq;
-            float w = 1.0f - u - v;
-            vec3 lp = v3(tr.v[0]) * u + v3(tr.v[1]) * v + v3(tr.v[2]) * w;
-            ls.direction = lp - surfacePos;
-            ls.dist = length(ls.direction);
-            float distSq = ls.dist * ls.dist;
-            ls.direction /= ls.dist;
-            vec3 e1 = v3(tr.v[1]) - v3(tr.v[0]);
-            vec3 e2 = v3(tr.v[2]) - v3(tr.v[0]);
-            ls.normal = normalize(cross(e1, e2));
-            ls.emission = v3(sc.mats[tr.material_idx].emission);
-            float cos_theta = fabsf(dot(ls.normal, -ls.direction));
-            float areaPdf = distSq / (et.area * fmaxf(cos_theta, 0.0001f));
-            ls.pdf = selectProb * areaPdf;
-        }
-        if (dot(ls.direction, ls.normal) < 0.0f) {
-            Ray sr{surfacePos, ls.direction};
-            if (cn) cn->shadow_rays++;
-            Hit sh = hit_meshes(sc, sr, true, cn);
-            bool inShadow = sh.did_hit && sh.t < ls.dist - EPS;
-            if (!inShadow) {
-                float bpdf;
-                vec3 f = DisneyEval(rec.mat, rec.eta, -r.d, rec.ffnormal, ls.direction, bpdf);
-                float weight = 1.0f;
-                if (!isDelta && ls.pdf > 0.0f) weight = PowerHeuristic(ls.pdf, bpdf);
-                if (bpdf > 0.0f) Li += weight * f * ls.emission / ls.pdf;
-            }
-        }
+    if (numOfLights <= 0) return lp;
+    LightSample ls;
+    float light_rand = pcg(seed);
+    int light_index = int(light_rand * float(numOfLights));
+    lp.light_index = light_index;
+    if (light_index < num_point) {
+        const rt_light& lt = sc.lights[size_t(light_index)];
+        isDelta = (int(lt.type) == 0);
+        ls.direction = v3(lt.position) - surfacePos;  // SamplePointLight :216-225
+        ls.dist = length(ls.direction);
+        float distSq = ls.dist * ls.dist;
+        ls.direction /= ls.dist;
+        ls.normal = -ls.direction;
+        ls.emission = v3(lt.emission);
+        ls.pdf = 1.0f / distSq;
+        ls.pdf *= float(numOfLights);
+    } else {
+        float cdf_rand = pcg(seed);
+        float triProb;
+        int tri_idx = SampleMeshCDF(sc, flags, cdf_rand, triProb);
+        lp.tri = tri_idx;
+        float selectProb = (float(num_mesh) / float(numOfLights)) * triProb;
+        // reading past the emissive table (possible only with the padded-CDF quirk) yields zeros
+        rt_emissive_tri et{0, 0, 0.0f, 0.0f};
+        if (size_t(tri_idx) < sc.emissive.size()) et = sc.emissive[size_t(tri_idx)];
+        const rt_triangle& tr = sc.tris[et.tri_index];  // SampleMeshLight :230-264
+        float r1 = pcg(seed);
+        float r2 = pcg(seed);
+        float sq = sqrtf(r1);
+        float u = 1.0f - sq;
+        float v = r2 * sq;
+        float w = 1.0f - u - v;
+        vec3 lpnt = v3(tr.v[0]) * u + v3(tr.v[1]) * v + v3(tr.v[2]) * w;
+        ls.direction = lpnt - surfacePos;
+        ls.dist = length(ls.direction);
+        float distSq = ls.dist * ls.dist;
+        ls.direction /= ls.dist;
+        vec3 e1 = v3(tr.v[1]) - v3(tr.v[0]);
+        vec3 e2 = v3(tr.v[2]) - v3(tr.v[0]);
+        ls.normal = normalize(cross(e1, e2));
+        ls.emission = v3(sc.mats[tr.material_idx].emission);
+        float cos_theta = fabsf(dot(ls.normal, -ls.direction));
+        float areaPdf = distSq / (et.area * fmaxf(cos_theta, 0.0001f));
+        ls.pdf = selectProb * areaPdf;
     }
-    return Li;
+    lp.origin = surfacePos;
+    lp.direction = ls.direction;
+    lp.dist = ls.dist;
+    lp.light_pdf = ls.pdf;
+    if (dot(ls.direction, ls.normal) < 0.0f) {
+        lp.traced = true;
+        float bpdf;
+        vec3 f = DisneyEval(rec.mat, rec.eta, -r.d, rec.ffnormal, ls.direction, bpdf);
+        lp.bsdf_pdf = bpdf;
+        float weight = 1.0f;
+        if (!isDelta && ls.pdf > 0.0f) weight = PowerHeuristic(ls.pdf, bpdf);
+        if (bpdf > 0.0f) lp.Li = weight * f * ls.emission / ls.pdf;
+    }
+    return lp;
 }
 
 // ---------------------------------------------------------------- path (main.comp:122-213)
-vec3 ray_color(const Scene& sc, uint32_t flags, uint32_t max_bounces, Ray ray, uint32_t& seed, Counters* cn) {
-    vec3 radiance = V(0.0f), throughput = V(1.0f);
+// State of a path when it arrives at a vertex: the ray of this bounce, what its closest-hit search found, and what the
+// path carries (throughput, pdf of the BSDF sample that produced the ray, RNG state).
+struct VertexState { Ray ray; Hit hit; vec3 throughput; float bsdfPdf; uint32_t seed; };
+
+// Everything ray_color does at one vertex (main.comp:137-209) apart from tracing rays.
+struct VertexResult {
+    vec3 emitted{};            // added to the radiance before the light sample: sky on a miss, MIS-weighted emission on a hit
+    LightPick light;           // the light sample; its contribution is light.Li * light_throughput when unoccluded
+    vec3 light_throughput{};   // throughput after the absorption step (main.comp:182-184)
+    bool alive = false;        // the path continues along `next`
+    Ray next{};
+    vec3 throughput{};         // after the BSDF sample and Russian roulette
+    float pdf = 0.0f;          // bsdfPdf carried to the next vertex
+    uint32_t seed = 0;         // RNG state after this vertex's draws
+    int lobe = -1;             // 0 diffuse, 1 specular reflection, 2 specular refraction, 3 clearcoat; -1 on a miss
+    float roughness = 0.0f;    // roughness the BSDF used (after texture modulation and the 0.001 clamp)
+};
+
+VertexResult shade_vertex(const Scene& sc, uint32_t flags, uint32_t bounce, VertexState st) {
+    VertexResult out;
+    const Ray& ray = st.ray;
+    Hit& hit = st.hit;
+    vec3 throughput = st.throughput;
+    uint32_t seed = st.seed;
     int numOfLights = int(sc.lights.size() + sc.emissive.size());
+    out.throughput = throughput; out.pdf = st.bsdfPdf; out.seed = seed; out.light_throughput = throughput;
+    if (!hit.did_hit) {
+        vec4 bg = sample_cube(sc, ray.d);
+        out.emitted = vec3{bg.x, bg.y, bg.z} * throughput;
+        return out;
+    }
+    rt_material& m = hit.mat;
+    vec3 emission = v3(m.emission);
+    if (m.base_color_tex != RT_NO_TEXTURE) {
+        vec4 t = sample2d(sc, m.base_color_tex, hit.uv);
+        m.base_colour[0] *= t.x; m.base_colour[1] *= t.y; m.base_colour[2] *= t.z; m.base_colour[3] *= t.w;
+    }
+    if (m.metallic_roughness_tex != RT_NO_TEXTURE) {
+        vec4 t = sample2d(sc, m.metallic_roughness_tex, hit.uv);
+        m.metallic *= t.z;
+        m.roughness *= t.y;
+    }
+    if (m.emission_tex != RT_NO_TEXTURE) {
+        vec4 t = sample2d(sc, m.emission_tex, hit.uv);
+        emission = emission * vec3{t.x, t.y, t.z};
+        m.emission[0] = emission.x; m.emission[1] = emission.y; m.emission[2] = emission.z;
+    }
+    if (m.normal_tex != RT_NO_TEXTURE) {
+        vec4 t = sample2d(sc, m.normal_tex, hit.uv);
+        vec3 tn = vec3{t.x, t.y, t.z} * 2.0f - V(1.0f);
+        hit.normal = normalize(hit.tangent * tn.x + hit.bitangent * tn.y + hit.normal * tn.z);
+    }
+    hit.ffnormal = dot(hit.normal, ray.d) <= 0.0f ? hit.normal : -hit.normal;
+    m.roughness = fmaxf(m.roughness, 0.001f);
+    out.roughness = m.roughness;
+    hit.eta = dot(hit.normal, hit.ffnormal) > 0.0f ? (1.0f / m.ior) : m.ior;
+
+    float misWeight = 1.0f;
+    if (bounce > 0) {
+        float lightPdf = MeshLightPdf(sc, hit, ray.d, numOfLights);
+        if (lightPdf > 0.0f) misWeight = PowerHeuristic(st.bsdfPdf, lightPdf);
+    }
+    out.emitted = misWeight * emission * throughput;
+
+    if (dot(hit.normal, hit.ffnormal) < 0.0f && m.spec_trans > 0.0f) {
+        vec3 bc = base(m);
+        if (flags & F_FIX_ABSORPTION)
+            throughput *= vec3{m_exp(m_log(bc.x) * hit.t), m_exp(m_log(bc.y) * hit.t), m_exp(m_log(bc.z) * hit.t)};
+        else
+            throughput *= vec3{m_exp(-m_log(bc.x) * hit.t), m_exp(-m_log(bc.y) * hit.t), m_exp(-m_log(bc.z) * hit.t)};
+    }
+    out.light_throughput = throughput;
+    out.light = SampleDirect(sc, flags, ray, hit, seed, numOfLights);
+
+    vec3 L;
+    float pdf;
+    float r1 = pcg(seed);
+    float r2 = pcg(seed);
+    vec3 f = DisneySample(m, hit.eta, -ray.d, hit.ffnormal, r1, r2, L, pdf, &out.lobe);
+    out.seed = seed;
+    out.throughput = throughput;
+    out.pdf = pdf;
+    if (!(pdf > 0.0f)) return out;
+    throughput *= f / pdf;
+    out.throughput = throughput;
+    if (bounce > 2) {
+        float p = fmaxf(0.05f, fminf(0.95f, fmaxf(throughput.x, fmaxf(throughput.y, throughput.z))));
+        bool kill = pcg(seed) > p;
+        out.seed = seed;
+        if (kill) return out;
+        throughput /= p;
+        out.throughput = throughput;
+    }
+    out.alive = true;
+    out.next.d = L;
+    out.next.o = hit.pos + L * EPSILON;
+    return out;
+}
+
+// Optional tap: the state of the path on arrival at vertex `bounce` (left untouched when the path ends earlier).
+struct PathTap { uint32_t bounce; bool reached; VertexState state; };
+
+vec3 ray_color(const Scene& sc, uint32_t flags, uint32_t max_bounces, Ray ray, uint32_t& seed, Counters* cn, PathTap* tap = nullptr) {
+    vec3 radiance = V(0.0f), throughput = V(1.0f);
     float bsdfPdf = 0.0f;
     for (uint32_t bounce = 0; bounce < max_bounces; ++bounce) {
         if (cn) cn->rays++;
         Hit hit = hit_meshes(sc, ray, false, cn);
-        if (!hit.did_hit) {
-            vec4 bg = sample_cube(sc, ray.d);
-            radiance += vec3{bg.x, bg.y, bg.z} * throughput;
-            break;
+        VertexState st{ray, hit, throughput, bsdfPdf, seed};
+        if (tap && tap->bounce == bounce) { tap->reached = true; tap->state = st; }
+        VertexResult vr = shade_vertex(sc, flags, bounce, st);
+        seed = vr.seed;
+        radiance += vr.emitted;
+        if (!hit.did_hit) break;
+        // DirectLight (disney.comp:697-713): the sample counts unless something opaque lies in front of the light
+        vec3 Ld = V(0.0f);
+        if (vr.light.traced) {
+            Ray sr{vr.light.origin, vr.light.direction};
+            if (cn) cn->shadow_rays++;
+            Hit sh = hit_meshes(sc, sr, true, cn);
+            bool inShadow = sh.did_hit && sh.t < vr.light.dist - EPS;
+            if (!inShadow) Ld = vr.light.Li;
         }
-        rt_material& m = hit.mat;
-        vec3 emission = v3(m.emission);
-        if (m.base_color_tex != RT_NO_TEXTURE) {
-            vec4 t = sample2d(sc, m.base_color_tex, hit.uv);
-            m.base_colour[0] *= t.x; m.base_colour[1] *= t.y; m.base_colour[2] *= t.z; m.base_colour[3] *= t.w;
-        }
-        if (m.metallic_roughness_tex != RT_NO_TEXTURE) {
-            vec4 t = sample2d(sc, m.metallic_roughness_tex, hit.uv);
-            m.metallic *= t.z;
-            m.roughness *= t.y;
-        }
-        if (m.emission_tex != RT_NO_TEXTURE) {
-            vec4 t = sample2d(sc, m.emission_tex, hit.uv);
-            emission = emission * vec3{t.x, t.y, t.z};
-            m.emission[0] = emission.x; m.emission[1] = emission.y; m.emission[2] = emission.z;
-        }
-        if (m.normal_tex != RT_NO_TEXTURE) {
-            vec4 t = sample2d(sc, m.normal_tex, hit.uv);
-            vec3 tn = vec3{t.x, t.y, t.z} * 2.0f - V(1.0f);
-            hit.normal = normalize(hit.tangent * tn.x + hit.bitangent * tn.y + hit.normal * tn.z);
-        }
-        hit.ffnormal = dot(hit.normal, ray.d) <= 0.0f ? hit.normal : -hit.normal;
-        m.roughness = fmaxf(m.roughness, 0.001f);
-        hit.eta = dot(hit.normal, hit.ffnormal) > 0.0f ? (1.0f / m.ior) : m.ior;
-
-        float misWeight = 1.0f;
-        if (bounce > 0) {
-            float lightPdf = MeshLightPdf(sc, hit, ray.d, numOfLights);
-            if (lightPdf > 0.0f) misWeight = PowerHeuristic(bsdfPdf, lightPdf);
-        }
-        radiance += misWeight * emission * throughput;
-
-        if (dot(hit.normal, hit.ffnormal) < 0.0f && m.spec_trans > 0.0f) {
-            vec3 bc = base(m);
-            if (flags & F_FIX_ABSORPTION)
-                throughput *= vec3{expf(logf(bc.x) * hit.t), expf(logf(bc.y) * hit.t), expf(logf(bc.z) * hit.t)};
-            else
-                throughput *= vec3{expf(-logf(bc.x) * hit.t), expf(-logf(bc.y) * hit.t), expf(-logf(bc.z) * hit.t)};
-        }
-
-        radiance += DirectLight(sc, flags, ray, hit, seed, numOfLights, cn) * throughput;
-
-        vec3 L;
-        float pdf;
-        float r1 = pcg(seed);
-        float r2 = pcg(seed);
-        vec3 f = DisneySample(m, hit.eta, -ray.d, hit.ffnormal, r1, r2, L, pdf);
-        if (pdf > 0.0f) throughput *= f / pdf;
-        else break;
-        bsdfPdf = pdf;
-        if (bounce > 2) {
-            float p = fmaxf(0.05f, fminf(0.95f, fmaxf(throughput.x, fmaxf(throughput.y, throughput.z))));
-            if (pcg(seed) > p) break;
-            throughput /= p;
-        }
-        ray.d = L;
-        ray.o = hit.pos + ray.d * EPSILON;
+        radiance += Ld * vr.light_throughput;
+        if (!vr.alive) break;
+        throughput = vr.throughput;
+        bsdfPdf = vr.pdf;
+        ray = vr.next;
     }
     return radiance;
 }
@@ -812,6 +904,10 @@ void* orc_scene_create(const void* blob, const uint64_t sizes[6], uint32_t n_bvh
     return sc;
 }
 void orc_scene_destroy(void* s) { delete static_cast<Scene*>(s); }
+
+// Nudges the results of sin / cos / {log, exp, pow} inside the shading code by that many ulp (see the sensitivity probe
+// above). Not thread-safe and meant for orc_shade_vertices only; (0, 0, 0) restores the library functions.
+void orc_set_libm_bias(int sin_ulp, int cos_ulp, int other_ulp) { g_bias_sin = sin_ulp; g_bias_cos = cos_ulp; g_bias_other = other_ulp; }
 
 // Installs (or, with nullptr, removes) a caller-owned array of one counter per reference-layout BVH node; every node
 // popped by hit_meshes increments its counter.
@@ -933,6 +1029,75 @@ void orc_render_radiance(const void* s, const rt_camera* cam, uint32_t frame, ui
             cnt->tri_tests += c.tri_tests; cnt->shadow_node_pops += c.shadow_node_pops; cnt->shadow_leaf_pops += c.shadow_leaf_pops;
             cnt->shadow_tri_tests += c.shadow_tri_tests;
         }
+    }
+}
+
+// State of every pixel's path of frame `frame` on arrival at vertex `bounce` (after that bounce's closest-hit search),
+// in the record the product's stage probe takes. reached[i] = 0 for paths that ended earlier (their record is zeroed).
+void orc_path_states(const void* s, const rt_camera* cam, uint32_t frame, uint32_t max_bounces, uint32_t flags, uint32_t bounce,
+                     rt_shade_vertex* out, uint8_t* reached, uint32_t threads) {
+    const Scene& sc = *static_cast<const Scene*>(s);
+    uint32_t W = cam->resolution[0], H = cam->resolution[1];
+    uint32_t nt = threads ? threads : std::max(1u, std::thread::hardware_concurrency());
+    parallel_rows(H, nt, [&](uint32_t y, uint32_t) {
+        for (uint32_t x = 0; x < W; ++x) {
+            uint32_t seed = pixel_seed(*cam, x, y, frame);
+            Ray r = generate_ray(*cam, x, y, seed);
+            PathTap tap{bounce, false, {}};
+            (void)ray_color(sc, flags, max_bounces, r, seed, nullptr, &tap);
+            size_t i = size_t(y) * W + x;
+            std::memset(&out[i], 0, sizeof(out[i]));
+            reached[i] = tap.reached ? 1 : 0;
+            if (!tap.reached) continue;
+            const VertexState& st = tap.state;
+            rt_shade_vertex& o = out[i];
+            o.ray_o[0] = st.ray.o.x; o.ray_o[1] = st.ray.o.y; o.ray_o[2] = st.ray.o.z; o.prev_pdf = st.bsdfPdf;
+            o.ray_d[0] = st.ray.d.x; o.ray_d[1] = st.ray.d.y; o.ray_d[2] = st.ray.d.z; o.seed = st.seed;
+            o.throughput[0] = st.throughput.x; o.throughput[1] = st.throughput.y; o.throughput[2] = st.throughput.z;
+            if (st.hit.did_hit) o.hit = rt_hit{st.hit.t, st.hit.u, st.hit.v, st.hit.prim};
+            else o.hit = rt_hit{INF, 0.0f, 0.0f, 0xFFFFFFFFu};
+        }
+    });
+}
+
+// shade_vertex on caller-supplied vertices: the twin of the product's rt_shade_vertices. The hit is rebuilt from
+// (prim, ray) with hit_triangle, which reproduces t, u, v bit for bit for a hit that came from hit_meshes; a record whose
+// triangle the ray does not hit at all is treated as a miss. The light sample is reported as the shader would trace it
+// (has_shadow = the light faces the surface), with the contribution it makes if unoccluded.
+void orc_shade_vertices(const void* s, uint32_t n, uint32_t bounce, uint32_t flags, const rt_shade_vertex* in, rt_shade_result* out) {
+    const Scene& sc = *static_cast<const Scene*>(s);
+    for (uint32_t i = 0; i < n; ++i) {
+        const rt_shade_vertex& v = in[i];
+        VertexState st;
+        st.ray = Ray{v3(v.ray_o), v3(v.ray_d)};
+        st.throughput = v3(v.throughput);
+        st.bsdfPdf = v.prev_pdf;
+        st.seed = v.seed;
+        if (v.hit.prim != 0xFFFFFFFFu && v.hit.prim < sc.tris.size()) {
+            const rt_triangle& tr = sc.tris[v.hit.prim];
+            const rt_material& m = sc.mats[tr.material_idx];
+            Hit h;
+            if (hit_triangle(tr, st.ray, m.shade_smooth != 0, h)) { h.prim = v.hit.prim; h.mat = m; h.has_mat = true; st.hit = h; }
+        }
+        VertexResult r = shade_vertex(sc, flags, bounce, st);
+        rt_shade_result& o = out[i];
+        std::memset(&o, 0, sizeof(o));
+        o.emitted[0] = r.emitted.x; o.emitted[1] = r.emitted.y; o.emitted[2] = r.emitted.z; o.seed = r.seed;
+        o.throughput[0] = r.throughput.x; o.throughput[1] = r.throughput.y; o.throughput[2] = r.throughput.z; o.pdf = r.pdf;
+        o.next_o[0] = r.next.o.x; o.next_o[1] = r.next.o.y; o.next_o[2] = r.next.o.z; o.alive = r.alive ? 1u : 0u;
+        o.next_d[0] = r.next.d.x; o.next_d[1] = r.next.d.y; o.next_d[2] = r.next.d.z; o.has_shadow = r.light.traced ? 1u : 0u;
+        o.shadow_o[0] = r.light.origin.x; o.shadow_o[1] = r.light.origin.y; o.shadow_o[2] = r.light.origin.z;
+        o.shadow_tmax = r.light.dist - EPS;
+        o.shadow_d[0] = r.light.direction.x; o.shadow_d[1] = r.light.direction.y; o.shadow_d[2] = r.light.direction.z;
+        o.light_index = r.light.light_index;
+        vec3 c = r.light.Li * r.light_throughput;
+        o.shadow_contrib[0] = c.x; o.shadow_contrib[1] = c.y; o.shadow_contrib[2] = c.z;
+        o.lobe = r.lobe;
+        o.light_tri = r.light.tri;
+        o.light_pdf = r.light.light_pdf;
+        o.bsdf_pdf_light = r.light.bsdf_pdf;
+        o.roughness = r.roughness;
+        o.medium_throughput[0] = r.light_throughput.x; o.medium_throughput[1] = r.light_throughput.y; o.medium_throughput[2] = r.light_throughput.z;
     }
 }
 

@@ -60,6 +60,15 @@ def _f(a, last=None):
 
 
 HIT = np.dtype([("t", "<f4"), ("u", "<f4"), ("v", "<f4"), ("prim", "<u4")])
+# stage-probe records of include/rt_api.h (rt_shade_vertex, rt_shade_result)
+SHADE_VERTEX = np.dtype([("ray_o", "<f4", 3), ("prev_pdf", "<f4"), ("ray_d", "<f4", 3), ("seed", "<u4"), ("throughput", "<f4", 3),
+                         ("reserved", "<u4"), ("hit", HIT)])
+SHADE_RESULT = np.dtype([("emitted", "<f4", 3), ("seed", "<u4"), ("throughput", "<f4", 3), ("pdf", "<f4"), ("next_o", "<f4", 3),
+                         ("alive", "<u4"), ("next_d", "<f4", 3), ("has_shadow", "<u4"), ("shadow_o", "<f4", 3), ("shadow_tmax", "<f4"),
+                         ("shadow_d", "<f4", 3), ("light_index", "<i4"), ("shadow_contrib", "<f4", 3), ("lobe", "<i4"),
+                         ("light_tri", "<i4"), ("light_pdf", "<f4"), ("bsdf_pdf_light", "<f4"), ("roughness", "<f4"),
+                         ("medium_throughput", "<f4", 3), ("reserved", "<u4")])
+assert SHADE_VERTEX.itemsize == 64 and SHADE_RESULT.itemsize == 144
 
 
 class OracleScene:
@@ -139,6 +148,21 @@ class OracleScene:
                                   C.c_uint32(threads))
         return rgb, cnt.as_dict()
 
+    def path_states(self, frame, max_bounces, bounce, flags=0, threads=0):
+        """Every pixel's path of `frame` on arrival at vertex `bounce`: (SHADE_VERTEX records, reached mask)."""
+        n = self.npix
+        out = np.zeros(n, SHADE_VERTEX)
+        reached = np.zeros(n, np.uint8)
+        lib().orc_path_states(self.h, _p(self.cam), C.c_uint32(frame), C.c_uint32(max_bounces), C.c_uint32(flags), C.c_uint32(bounce),
+                              _p(out), _p(reached), C.c_uint32(threads))
+        return out, reached.astype(bool)
+
+    def shade_vertices(self, bounce, vertices, flags=0):
+        v = np.ascontiguousarray(vertices, dtype=SHADE_VERTEX)
+        out = np.zeros(len(v), SHADE_RESULT)
+        lib().orc_shade_vertices(self.h, C.c_uint32(len(v)), C.c_uint32(bounce), C.c_uint32(flags), _p(v), _p(out))
+        return out
+
     def render(self, n_frames, max_bounces, flags=0, first=0, stride=1, threads=0, sum_rgba=None, accum8=None):
         W, H = int(self.cam["resolution"][0][0]), int(self.cam["resolution"][0][1])
         if sum_rgba is None:
@@ -149,6 +173,11 @@ class OracleScene:
         lib().orc_render(self.h, _p(self.cam), C.c_uint32(first), C.c_uint32(stride), C.c_uint32(n_frames), C.c_uint32(max_bounces), C.c_uint32(flags),
                          _p(sum_rgba), _p(accum8), C.byref(cnt), C.c_uint32(threads))
         return sum_rgba, accum8, cnt.as_dict()
+
+
+def set_libm_bias(sin_ulp=0, cos_ulp=0, other_ulp=0):
+    """Nudges sin / cos / {log, exp, pow} inside the oracle's shading code by that many ulp (conditioning probe)."""
+    lib().orc_set_libm_bias(C.c_int(sin_ulp), C.c_int(cos_ulp), C.c_int(other_ulp))
 
 
 def pcg_floats(seed, n):

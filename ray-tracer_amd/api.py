@@ -31,6 +31,14 @@ CAMERA = np.dtype([("resolution", "<u4", 2), ("view_port_uv", "<f4", 2), ("focal
                    ("_pad", "<u4", 4)])
 HIT = np.dtype([("t", "<f4"), ("u", "<f4"), ("v", "<f4"), ("prim", "<u4")])
 assert BVH_NODE.itemsize == 32 and TRIANGLE.itemsize == 144 and MATERIAL.itemsize == 96
+SHADE_VERTEX = np.dtype([("ray_o", "<f4", 3), ("prev_pdf", "<f4"), ("ray_d", "<f4", 3), ("seed", "<u4"), ("throughput", "<f4", 3),
+                         ("reserved", "<u4"), ("hit", HIT)])
+SHADE_RESULT = np.dtype([("emitted", "<f4", 3), ("seed", "<u4"), ("throughput", "<f4", 3), ("pdf", "<f4"), ("next_o", "<f4", 3),
+                         ("alive", "<u4"), ("next_d", "<f4", 3), ("has_shadow", "<u4"), ("shadow_o", "<f4", 3), ("shadow_tmax", "<f4"),
+                         ("shadow_d", "<f4", 3), ("light_index", "<i4"), ("shadow_contrib", "<f4", 3), ("lobe", "<i4"),
+                         ("light_tri", "<i4"), ("light_pdf", "<f4"), ("bsdf_pdf_light", "<f4"), ("roughness", "<f4"),
+                         ("medium_throughput", "<f4", 3), ("reserved", "<u4")])
+assert SHADE_VERTEX.itemsize == 64 and SHADE_RESULT.itemsize == 144
 assert LIGHT.itemsize == 48 and EMISSIVE_TRI.itemsize == 16 and CAMERA.itemsize == 128 and HIT.itemsize == 16
 
 NO_TEXTURE = 0xFFFFFFFF
@@ -119,6 +127,7 @@ API = {
     "rt_reset_counters": (_I, [_P]),
     "rt_trace_closest": (_I, [_P, _U32, _P, _P, _P]),
     "rt_trace_shadow": (_I, [_P, _U32, _P, _P, _P, _P]),
+    "rt_shade_vertices": (_I, [_P, _U32, _U32, _P, _P]),
     "rt_bench_trace": (_I, [_P, _U32, _P, _P, _I, _U32, _P]),
     "rt_generate_rays": (_I, [_P, _U32, _P, _P, _P]),
     "rt_eval_bsdf": (_I, [_P, _U32, _P, _P, _P, _P, _P, _P, _P]),

@@ -42,6 +42,7 @@ struct DevBuf {
         if (e == hipSuccess) bytes = n;
         return e;
     }
+    void swap(DevBuf& o) { std::swap(p, o.p); std::swap(bytes, o.bytes); }
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
@@ -54,9 +55,9 @@ struct DevBuf {
 // Grid sizes in 256-thread units per CU. Traversal runs RT_TRACE_WAVES_PER_EU waves per SIMD (the LDS each workgroup
 // needs for stack heads and resident node records sets how many fit); shading is bound by HBM, and two workgroups per
 // CU already saturate it while leaving slots to the other lane's traversal.
-// RT_HIP_TRACE_BLOCKS / RT_HIP_SHADE_BLOCKS override them for tuning runs.
-static uint32_t kTraceBlocksPerCu = RT_TRACE_WAVES_PER_EU;
-static uint32_t kShadeBlocksPerCu = 2;
+// RT_HIP_TRACE_BLOCKS / RT_HIP_SHADE_BLOCKS override them for tuning runs (read once per context, at creation).
+constexpr uint32_t kDefaultTraceBlocksPerCu = RT_TRACE_WAVES_PER_EU;
+constexpr uint32_t kDefaultShadeBlocksPerCu = 2;
 
 constexpr uint32_t kMaxLanes = 4;
 
@@ -95,7 +96,9 @@ struct rt_ctx {
     uint32_t slice_first = 0, slice_stride = 1;
     rt_camera cam{};
     bool have_scene = false, have_camera = false;
+    bool paths_ok = false;                    // path buffers match W x H (false after a resize that ran out of memory)
     int n_cu = 256;
+    uint32_t trace_blocks_per_cu = kDefaultTraceBlocksPerCu, shade_blocks_per_cu = kDefaultShadeBlocksPerCu;
 
     // scene
     DevBuf nodes, wide, isect, shade, mats, lights, light_tris, cdf, texels, tex_table, sky, srgb;
@@ -104,7 +107,7 @@ struct rt_ctx {
     Lane lanes[kMaxLanes];
     uint32_t n_lanes = 1, next_lane = 0;
     hipEvent_t call_mark = nullptr;
-    DevBuf stats, seeds;
+    DevBuf stats, seeds, probe;
     uint32_t shard_cap = 0;
     uint32_t slot_cap = 0;
     // output
@@ -295,8 +298,8 @@ int run_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t frames, uint32_t frame
                            frame_first, frame_stride, seeds_out);
     }
     uint32_t* queues[2] = {l.q0.as<uint32_t>(), l.q1.as<uint32_t>()};
-    const uint32_t trace_grid = trace_grid_for(c, n_slots, kTraceBlocksPerCu);
-    const uint32_t shade_grid = grid_for(c, n_slots, kShadeBlocksPerCu);
+    const uint32_t trace_grid = trace_grid_for(c, n_slots, c->trace_blocks_per_cu);
+    const uint32_t shade_grid = grid_for(c, n_slots, c->shade_blocks_per_cu);
     for (uint32_t b = 0; b < c->max_bounces; ++b) {
         const uint32_t* in_q = b == 0 ? nullptr : queues[b & 1];
         const uint32_t* in_n = b == 0 ? nullptr : l.q_count() + b;
@@ -340,6 +343,7 @@ int finish_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t n_slots) {
 int ready_to_render(rt_ctx* c) {
     if (!c->have_scene) return fail(c, RT_ERR_NO_SCENE, "no scene uploaded");
     if (!c->have_camera) return fail(c, RT_ERR_NO_SCENE, "no camera set");
+    if (!c->paths_ok) return fail(c, RT_ERR_OOM, "no path buffers: the last resize ran out of device memory");
     return RT_OK;
 }
 
@@ -384,8 +388,8 @@ extern "C" int rt_create(const rt_config* cfg, rt_ctx** out) {
     if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) c->n_cu = std::max(1, prop.multiProcessorCount);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return bail(RT_ERR_DEVICE); }
     c->n_lanes = (c->flags & (RT_SINGLE_STREAM | RT_KERNEL_TIMING | RT_REF_RGBA8_ACCUM)) ? 1 : 2;
-    if (const char* env = std::getenv("RT_HIP_TRACE_BLOCKS")) kTraceBlocksPerCu = uint32_t(std::max(1, std::atoi(env)));
-    if (const char* env = std::getenv("RT_HIP_SHADE_BLOCKS")) kShadeBlocksPerCu = uint32_t(std::max(1, std::atoi(env)));
+    if (const char* env = std::getenv("RT_HIP_TRACE_BLOCKS")) c->trace_blocks_per_cu = uint32_t(std::max(1, std::atoi(env)));
+    if (const char* env = std::getenv("RT_HIP_SHADE_BLOCKS")) c->shade_blocks_per_cu = uint32_t(std::max(1, std::atoi(env)));
     if (const char* env = std::getenv("RT_HIP_LANES")) {   // tuning aid: 1..4 concurrent passes
         int v = std::atoi(env);
         if (v >= 1 && v <= int(kMaxLanes) && !(c->flags & RT_KERNEL_TIMING)) c->n_lanes = uint32_t(v);
@@ -397,6 +401,7 @@ extern "C" int rt_create(const rt_config* cfg, rt_ctx** out) {
     }
     if (hipEventCreateWithFlags(&c->call_mark, hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return bail(RT_ERR_DEVICE); }
     if ((rc = alloc_paths(c)) != RT_OK) return bail(rc);
+    c->paths_ok = true;
     if (c->stats.ensure(sizeof(TraceStats)) != hipSuccess) { c->err = "counter allocation failed"; return bail(RT_ERR_OOM); }
     (void)hipMemsetAsync(c->stats.p, 0, c->stats.bytes, c->stream);
     // sRGB decode table, identical to what a CPU evaluation computes: exact curve in double, rounded once
@@ -471,21 +476,28 @@ extern "C" int rt_upload_scene(rt_ctx* c, const void* blob, const uint64_t sizes
         o[12] = q.a[3];   o[13] = q.b[3];   o[14] = q.c[3];    o[15] = m.emission[2];
     }
 
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // Every table is staged in a fresh buffer and all of them are committed together, so an upload that fails half-way
+    // (out of memory, a failed copy) leaves the previous scene in place and renderable.
+    DevBuf nb_nodes, nb_wide, nb_isect, nb_shade, nb_mats, nb_lights, nb_lt, nb_cdf;
     auto put = [&](DevBuf& b, const void* src, size_t bytes) -> hipError_t {
         hipError_t e = b.ensure(bytes);
         if (e != hipSuccess) return e;
         if (bytes) e = hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice);
         return e;
     };
-    HIPCHK(c, put(c->nodes, gs.nodes.data(), gs.nodes.size() * sizeof(rtint::NodePair)));
-    HIPCHK(c, put(c->wide, gs.wide.data(), gs.wide.size() * sizeof(rtint::NodeQuad)));
-    HIPCHK(c, put(c->isect, gs.isect.data(), gs.isect.size() * sizeof(rtint::TriIsect)));
-    HIPCHK(c, put(c->shade, gs.shade.data(), gs.shade.size() * sizeof(rtint::TriShade)));
-    HIPCHK(c, put(c->mats, mats, size_t(n_mat) * sizeof(rt_material)));
-    HIPCHK(c, put(c->lights, lights, size_t(n_light) * sizeof(rt_light)));
-    HIPCHK(c, put(c->light_tris, lt.data(), lt.size() * 4));
-    HIPCHK(c, put(c->cdf, cdf, size_t(n_emissive) * 4));
+    HIPCHK(c, put(nb_nodes, gs.nodes.data(), gs.nodes.size() * sizeof(rtint::NodePair)));
+    HIPCHK(c, put(nb_wide, gs.wide.data(), gs.wide.size() * sizeof(rtint::NodeQuad)));
+    HIPCHK(c, put(nb_isect, gs.isect.data(), gs.isect.size() * sizeof(rtint::TriIsect)));
+    HIPCHK(c, put(nb_shade, gs.shade.data(), gs.shade.size() * sizeof(rtint::TriShade)));
+    HIPCHK(c, put(nb_mats, mats, size_t(n_mat) * sizeof(rt_material)));
+    HIPCHK(c, put(nb_lights, lights, size_t(n_light) * sizeof(rt_light)));
+    HIPCHK(c, put(nb_lt, lt.data(), lt.size() * 4));
+    HIPCHK(c, put(nb_cdf, cdf, size_t(n_emissive) * 4));
+    // nothing queued earlier may still read the tables about to be replaced (every pass on a lane is followed by its
+    // accumulation on the main stream, so the main stream is the last to finish)
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->nodes.swap(nb_nodes); c->wide.swap(nb_wide); c->isect.swap(nb_isect); c->shade.swap(nb_shade);
+    c->mats.swap(nb_mats); c->lights.swap(nb_lights); c->light_tris.swap(nb_lt); c->cdf.swap(nb_cdf);
 
     SceneDev& sd = c->sd;
     sd.nodes = c->nodes.as<float4>(); sd.isect = c->isect.as<float4>(); sd.shade = c->shade.as<float4>();
@@ -536,7 +548,7 @@ extern "C" int rt_upload_textures(rt_ctx* c, const rt_texture* textures, uint32_
         HIPCHK(c, c->sky.ensure(bytes));
         HIPCHK(c, hipMemcpy(c->sky.p, skybox->pixels, bytes, hipMemcpyHostToDevice));
         tv.sky_w = skybox->width; tv.sky_h = skybox->height;
-    } else if (!c->sky.p) {
+    } else {
         const uint32_t white[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
         HIPCHK(c, c->sky.ensure(sizeof(white)));
         HIPCHK(c, hipMemcpy(c->sky.p, white, sizeof(white), hipMemcpyHostToDevice));
@@ -565,8 +577,23 @@ extern "C" int rt_resize(rt_ctx* c, uint32_t w, uint32_t h) {
     int rc;
     if ((rc = bind_device(c)) != RT_OK) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    const uint32_t old_w = c->W, old_h = c->H;
     c->W = w; c->H = h; c->npix = w * h;
-    if ((rc = alloc_paths(c)) != RT_OK) return rc;
+    c->paths_ok = false;
+    if ((rc = alloc_paths(c)) != RT_OK) {
+        // go back to the previous resolution; if even that fails the context refuses to render until a resize succeeds
+        const std::string why = c->err;
+        c->W = old_w; c->H = old_h; c->npix = old_w * old_h;
+        (void)hipGetLastError();
+        if (alloc_paths(c) == RT_OK) {
+            c->paths_ok = true;
+            refresh_camera(c);
+            (void)clear_accum(c);
+            return fail(c, rc, why + " (resolution left at " + std::to_string(old_w) + "x" + std::to_string(old_h) + ")");
+        }
+        return fail(c, rc, why + " (path buffers lost: resize again before rendering)");
+    }
+    c->paths_ok = true;
     refresh_camera(c);
     return clear_accum(c);
 }
@@ -753,8 +780,8 @@ static int trace_common(rt_ctx* c, uint32_t n, const float* origins, const float
     HIPCHK(c, hipMemsetAsync(c->aux_cursor(), 0, 4, c->stream));
     {
         StageTimer tm(c, shadow ? ST_CONNECT : ST_EXTEND);
-        if (count) hipLaunchKernelGGL(k_trace_rays<true>, dim3(trace_grid_for(c, n, kTraceBlocksPerCu)), dim3(kTraceBlock), 0, c->stream, c->sd, ro.as<float4>(), rd.as<float4>(), n, shadow, hits.as<float4>(), RT_CURSOR(c->aux_cursor()), c->tstats());
-        else hipLaunchKernelGGL(k_trace_rays<false>, dim3(trace_grid_for(c, n, kTraceBlocksPerCu)), dim3(kTraceBlock), 0, c->stream, c->sd, ro.as<float4>(), rd.as<float4>(), n, shadow, hits.as<float4>(), RT_CURSOR(c->aux_cursor()), c->tstats());
+        if (count) hipLaunchKernelGGL(k_trace_rays<true>, dim3(trace_grid_for(c, n, c->trace_blocks_per_cu)), dim3(kTraceBlock), 0, c->stream, c->sd, ro.as<float4>(), rd.as<float4>(), n, shadow, hits.as<float4>(), RT_CURSOR(c->aux_cursor()), c->tstats());
+        else hipLaunchKernelGGL(k_trace_rays<false>, dim3(trace_grid_for(c, n, c->trace_blocks_per_cu)), dim3(kTraceBlock), 0, c->stream, c->sd, ro.as<float4>(), rd.as<float4>(), n, shadow, hits.as<float4>(), RT_CURSOR(c->aux_cursor()), c->tstats());
     }
     end_call(c);
     HIPCHK(c, hipGetLastError());
@@ -801,7 +828,7 @@ extern "C" int rt_bench_trace(rt_ctx* c, uint32_t n, const float* origins, const
     HIPCHK(c, hipEventCreate(&b));
     auto launch = [&] {
         (void)hipMemsetAsync(c->aux_cursor(), 0, 4, c->stream);
-        hipLaunchKernelGGL(k_trace_rays<false>, dim3(trace_grid_for(c, n, kTraceBlocksPerCu)), dim3(kTraceBlock), 0, c->stream, c->sd, ro.as<float4>(), rd.as<float4>(), n, shadow, hits.as<float4>(), RT_CURSOR(c->aux_cursor()), c->tstats());
+        hipLaunchKernelGGL(k_trace_rays<false>, dim3(trace_grid_for(c, n, c->trace_blocks_per_cu)), dim3(kTraceBlock), 0, c->stream, c->sd, ro.as<float4>(), rd.as<float4>(), n, shadow, hits.as<float4>(), RT_CURSOR(c->aux_cursor()), c->tstats());
     };
     launch();  // warm-up
     (void)hipEventRecord(a, c->stream);
@@ -830,6 +857,7 @@ extern "C" int rt_generate_rays(rt_ctx* c, uint32_t frame, float* origins, float
     if (!c) return RT_ERR_INVALID;
     if (!origins || !directions) return fail(c, RT_ERR_INVALID, "rt_generate_rays: null argument");
     if (!c->have_camera) return fail(c, RT_ERR_NO_SCENE, "no camera set");
+    if (!c->paths_ok) return fail(c, RT_ERR_OOM, "no path buffers: the last resize ran out of device memory");
     int rc;
     if ((rc = bind_device(c)) != RT_OK) return rc;
     hipLaunchKernelGGL(k_raygen, dim3(grid_for(c, c->npix, 8)), dim3(kBlock), 0, c->stream, c->cam, c->pd(), c->npix, c->npix, frame, 1u,
@@ -852,6 +880,89 @@ extern "C" int rt_render_radiance(rt_ctx* c, uint32_t frame, float* rgb) {
     if ((rc = finish_pass(c, c->lanes[0], c->stream, c->npix)) != RT_OK) return rc;
     end_call(c);
     return download_vec3(c, c->lanes[0].rad.as<float4>(), c->npix, rgb);
+}
+
+extern "C" int rt_shade_vertices(rt_ctx* c, uint32_t n, uint32_t bounce, const rt_shade_vertex* vin, rt_shade_result* vout) {
+    if (!c) return RT_ERR_INVALID;
+    if (n && (!vin || !vout)) return fail(c, RT_ERR_INVALID, "rt_shade_vertices: null argument");
+    if (!c->have_scene) return fail(c, RT_ERR_NO_SCENE, "no scene uploaded");
+    if (!c->paths_ok) return fail(c, RT_ERR_OOM, "no path buffers: the last resize ran out of device memory");
+    if (bounce >= c->max_bounces) return fail(c, RT_ERR_INVALID, "rt_shade_vertices: bounce must be below max_bounces");
+    if (n > c->slot_cap) return fail(c, RT_ERR_UNSUPPORTED, "rt_shade_vertices: more vertices than the context has path slots (width x height x frames per pass)");
+    int rc;
+    if ((rc = bind_device(c)) != RT_OK) return rc;
+    if (n == 0) return RT_OK;
+    // The vertices go into lane 0's path-state buffers, slot i = vertex i, exactly as raygen/extend would have left them
+    // (radiance zero, so what comes back is what this vertex added). The main stream is ordered behind every pass queued so far.
+    Lane& l = c->lanes[0];
+    std::vector<float4> ro(n), rd(n), hit(n), thr(n), rad(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        const rt_shade_vertex& v = vin[i];
+        ro[i] = make_float4(v.ray_o[0], v.ray_o[1], v.ray_o[2], 0.0f);
+        rd[i] = make_float4(v.ray_d[0], v.ray_d[1], v.ray_d[2], 0.0f);
+        uint32_t prim = v.hit.prim;
+        if (prim != kNoPrim && prim >= c->sd.n_tri) return fail(c, RT_ERR_INVALID, "rt_shade_vertices: vertex " + std::to_string(i) + " names a triangle the scene does not have");
+        hit[i] = make_float4(v.hit.t, v.hit.u, v.hit.v, 0.0f);
+        std::memcpy(&hit[i].w, &prim, 4);
+        thr[i] = make_float4(v.throughput[0], v.throughput[1], v.throughput[2], v.prev_pdf);
+        rad[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        std::memcpy(&rad[i].w, &v.seed, 4);
+    }
+    const size_t bytes = size_t(n) * sizeof(float4);
+    HIPCHK(c, c->probe.ensure(3 * bytes));
+    HIPCHK(c, hipMemcpyAsync(l.ray_o.p, ro.data(), bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(l.ray_d.p, rd.data(), bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(l.hit.p, hit.data(), bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(l.thr.p, thr.data(), bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(l.rad.p, rad.data(), bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(l.counts.p, 0, Lane::counts_words() * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->probe.p, 0, 3 * bytes, c->stream));
+    HIPCHK(c, hipMemsetAsync(l.sq_o.p, 0, bytes, c->stream));
+    HIPCHK(c, hipMemsetAsync(l.sq_d.p, 0, bytes, c->stream));
+    HIPCHK(c, hipMemsetAsync(l.sq_c.p, 0, bytes, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));     // the host vectors above are pageable: do not let them go before the copies ran
+    ShadeParams sp{bounce, c->max_bounces, c->flags, nullptr, nullptr, n, l.stage_next.as<uint32_t>(), l.shard_counts(bounce),
+                   l.stage_shadow.as<uint32_t>(), l.shard_counts(bounce) + kQueueShards, c->shard_cap, c->probe.as<uint4>()};
+    const uint32_t grid = grid_for(c, n, c->shade_blocks_per_cu);
+    if (c->sd.n_mat <= kLdsMats && c->sd.n_emissive <= kLdsLights) hipLaunchKernelGGL((k_shade<true, true>), dim3(grid), dim3(kBlock), 0, c->stream, c->sd, l.pd(), l.sq(), sp);
+    else hipLaunchKernelGGL((k_shade<false, true>), dim3(grid), dim3(kBlock), 0, c->stream, c->sd, l.pd(), l.sq(), sp);
+    HIPCHK(c, hipGetLastError());
+    std::vector<float4> so(n), sdir(n), scon(n);
+    std::vector<uint4> pr(3 * size_t(n));
+    HIPCHK(c, hipMemcpyAsync(ro.data(), l.ray_o.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(rd.data(), l.ray_d.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(thr.data(), l.thr.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(rad.data(), l.rad.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(so.data(), l.sq_o.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(sdir.data(), l.sq_d.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(scon.data(), l.sq_c.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(pr.data(), c->probe.p, 3 * bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (uint32_t i = 0; i < n; ++i) {
+        rt_shade_result& o = vout[i];
+        std::memset(&o, 0, sizeof(o));
+        const uint4 p0 = pr[3 * size_t(i)], p1 = pr[3 * size_t(i) + 1], p2 = pr[3 * size_t(i) + 2];
+        o.emitted[0] = rad[i].x; o.emitted[1] = rad[i].y; o.emitted[2] = rad[i].z;
+        std::memcpy(&o.seed, &rad[i].w, 4);
+        o.throughput[0] = thr[i].x; o.throughput[1] = thr[i].y; o.throughput[2] = thr[i].z; o.pdf = thr[i].w;
+        o.alive = p0.x & 1u;
+        o.has_shadow = (p0.x >> 1) & 1u;
+        if (o.alive) {
+            o.next_o[0] = ro[i].x; o.next_o[1] = ro[i].y; o.next_o[2] = ro[i].z;
+            o.next_d[0] = rd[i].x; o.next_d[1] = rd[i].y; o.next_d[2] = rd[i].z;
+        }
+        if (o.has_shadow) {
+            o.shadow_o[0] = so[i].x; o.shadow_o[1] = so[i].y; o.shadow_o[2] = so[i].z; o.shadow_tmax = so[i].w;
+            o.shadow_d[0] = sdir[i].x; o.shadow_d[1] = sdir[i].y; o.shadow_d[2] = sdir[i].z;
+            o.shadow_contrib[0] = scon[i].x; o.shadow_contrib[1] = scon[i].y; o.shadow_contrib[2] = scon[i].z;
+        }
+        o.light_index = int32_t(p0.y); o.lobe = int32_t(p0.z); o.light_tri = int32_t(p0.w);
+        std::memcpy(&o.light_pdf, &p1.x, 4);
+        std::memcpy(&o.bsdf_pdf_light, &p1.y, 4);
+        std::memcpy(&o.roughness, &p1.z, 4);
+        std::memcpy(&o.medium_throughput[0], &p2.x, 4); std::memcpy(&o.medium_throughput[1], &p2.y, 4); std::memcpy(&o.medium_throughput[2], &p2.z, 4);
+    }
+    return RT_OK;
 }
 
 static int bsdf_common(rt_ctx* c, uint32_t n, const rt_material* mats, const float* eta, const float* V, const float* N,

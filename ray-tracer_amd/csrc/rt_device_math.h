@@ -326,12 +326,14 @@ RT_DEV f3 disney_eval(const Mat& m, const ShadePoint& sp, f3 Lworld, float& out_
 }
 
 // DisneySample (disney.comp:476-558): picks a lobe with r1, samples it, returns f * |N.L|, the pdf and world-space L.
-RT_DEV f3 disney_sample(const Mat& m, const ShadePoint& sp, float r1, float r2, f3& Lworld, float& out_pdf) {
+// `lobe_out`, when given, receives the lobe chosen: 0 diffuse, 1 specular reflection, 2 specular refraction, 3 clearcoat.
+RT_DEV f3 disney_sample(const Mat& m, const ShadePoint& sp, float r1, float r2, f3& Lworld, float& out_pdf, int* lobe_out = nullptr) {
     out_pdf = 0.0f;
     f3 f = mk3(0.0f);
     f3 V = sp.V;
     LobeWeights w = lobe_weights(m, sp.spec_col, fresnel_mix(m, sp.eta, V.z));
     float c0 = w.diffuse, c1 = c0 + w.refl, c2 = c1 + w.refr;
+    if (lobe_out) *lobe_out = r1 < c0 ? 0 : (r1 < c1 ? 1 : (r1 < c2 ? 2 : 3));
     f3 L;
     if (r1 < c0) {
         r1 /= c0;

@@ -698,6 +698,9 @@ struct ShadeParams {
     uint32_t* shadow_stage;
     uint32_t* shadow_shard_counts;
     uint32_t shard_cap;
+    // k_shade<.., true> only: three records per slot, {alive | queued light sample << 1, light index, lobe, light-table entry},
+    // {light pdf, BSDF pdf for the light direction, roughness used, -} and {throughput after absorption, -}
+    uint4* probe;
 };
 
 constexpr uint32_t kQueueShards = 64;
@@ -709,7 +712,9 @@ constexpr uint32_t kLdsLights = 256;   // emissive triangles (CDF + light table)
 // LDS_TABLES: the material table, the light CDF and the light table are small (<= kLdsMats / kLdsLights entries) and are
 // copied into LDS once per workgroup, which removes three dependent global round trips (material fetch, the CDF binary
 // search, the light record) from every vertex. Larger scenes use the same code reading the tables from global memory.
-template <bool LDS_TABLES>
+// PROBE: the same code additionally records the discrete decisions taken at each vertex (which light, which lobe) and the
+// two pdfs of the light sample, for the stage-level entry point that checks this kernel vertex by vertex.
+template <bool LDS_TABLES, bool PROBE = false>
 __global__ __launch_bounds__(kBlock, RT_SHADE_WAVES) void k_shade(SceneDev sc, PathDev pd, ShadowQueue sq, ShadeParams sp) {
     __shared__ v4f s_mats[LDS_TABLES ? kLdsMats * 6 : 1];
     __shared__ v4f s_lt[LDS_TABLES ? kLdsLights * 4 : 1];
@@ -737,6 +742,9 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_WAVES) void k_shade(SceneDev sc, P
         bool alive = false, want_shadow = false;
         uint32_t slot = 0;
         float4 sh_o = {}, sh_d = {}, sh_c = {};
+        int probe_light = -1, probe_lobe = -1, probe_tri = -1;
+        float probe_lpdf = 0.0f, probe_bpdf = 0.0f, probe_rough = 0.0f;
+        f3 probe_thr = {0.0f, 0.0f, 0.0f};
         if (valid) {
             slot = sp.in_queue ? sp.in_queue[i] : i;
             float4 h4 = pd.hit[slot], o4 = pd.ray_o[slot], d4 = pd.ray_d[slot], T4 = pd.thr[slot], R4 = pd.rad[slot];
@@ -830,12 +838,14 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_WAVES) void k_shade(SceneDev sc, P
                 }
 
                 ShadePoint pt = make_shade_point(m, eta, -rd, ffn);
+                if (PROBE) { probe_rough = m.roughness; probe_thr = thr; }
 
                 // next-event estimation: DirectLight, disney.comp:623-720
                 if (num_lights > 0) {
                     f3 surface = pos + normal * kSurfEps;
                     float light_rand = pcg_next(seed);
                     int light_index = int(light_rand * float(num_lights));
+                    if (PROBE) probe_light = light_index;
                     f3 ldir, lnormal, lemit;
                     float ldist, lpdf;
                     bool delta = false, have = true;
@@ -869,6 +879,7 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_WAVES) void k_shade(SceneDev sc, P
                         // SampleMeshLight (disney.comp:230-264) on the device light table
                         float r1 = pcg_next(seed);
                         float r2 = pcg_next(seed);
+                        if (PROBE) probe_tri = lo;
                         if (uint32_t(lo) < sc.n_emissive) {
                             float4 L0, L1, L2, L3;
                             if (LDS_TABLES) {
@@ -897,6 +908,7 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_WAVES) void k_shade(SceneDev sc, P
                     if (have && dot(ldir, lnormal) < 0.0f) {
                         float bpdf;
                         f3 f = disney_eval(m, pt, ldir, bpdf);
+                        if (PROBE) { probe_lpdf = lpdf; probe_bpdf = bpdf; }
                         if (bpdf > 0.0f) {
                             float weight = 1.0f;
                             if (!delta && lpdf > 0.0f) weight = power_heuristic(lpdf, bpdf);
@@ -919,7 +931,8 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_WAVES) void k_shade(SceneDev sc, P
                     float r2 = pcg_next(seed);
                     f3 L;
                     float pdf;
-                    f3 f = disney_sample(m, pt, r1, r2, L, pdf);
+                    f3 f = disney_sample(m, pt, r1, r2, L, pdf, PROBE ? &probe_lobe : nullptr);
+                    if (PROBE) { pd.thr[slot] = make_float4(thr.x, thr.y, thr.z, pdf); }   // a path that ends here still reports its state
                     if (pdf > 0.0f) {
                         thr = thr * (f / pdf);
                         bool go = true;
@@ -928,6 +941,7 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_WAVES) void k_shade(SceneDev sc, P
                             if (pcg_next(seed) > p) go = false;
                             else thr = thr / p;
                         }
+                        if (PROBE) pd.thr[slot] = make_float4(thr.x, thr.y, thr.z, pdf);
                         if (go) {
                             alive = true;
                             f3 no = pos + L * kRayEps;
@@ -948,6 +962,11 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_WAVES) void k_shade(SceneDev sc, P
         if (want_shadow) {
             sq.o[slot] = sh_o; sq.d[slot] = sh_d; sq.c[slot] = sh_c;
             sp.shadow_stage[shard * sp.shard_cap + sdst] = slot;
+        }
+        if (PROBE && valid) {
+            sp.probe[3 * size_t(slot)] = make_uint4((alive ? 1u : 0u) | (want_shadow ? 2u : 0u), uint32_t(probe_light), uint32_t(probe_lobe), uint32_t(probe_tri));
+            sp.probe[3 * size_t(slot) + 1] = make_uint4(__float_as_uint(probe_lpdf), __float_as_uint(probe_bpdf), __float_as_uint(probe_rough), 0u);
+            sp.probe[3 * size_t(slot) + 2] = make_uint4(__float_as_uint(probe_thr.x), __float_as_uint(probe_thr.y), __float_as_uint(probe_thr.z), 0u);
         }
     }
 }

@@ -72,7 +72,16 @@ class HipRenderer:
         self._check(self.lib.rt_set_camera(self._ctx, ptr(cam)))
         self.scene = scene
 
-    reload_scene = upload_scene
+    # reload_scene (renderer.rs:193-231): the new scene is viewed from where the camera currently is
+    # (location and rotation are carried over, renderer.rs:194-196); everything else comes from the new scene.
+    def reload_scene(self, scene: Scene):
+        old = getattr(self, "scene", None)
+        if old is not None:
+            cam = np.ascontiguousarray(scene.camera).copy()
+            cam["location"][0] = old.camera["location"][0]
+            cam["rotation"][0] = old.camera["rotation"][0]
+            scene.camera = cam
+        self.upload_scene(scene)
 
     # set_camera_pose (renderer.rs:165-168): location + camera->world rotation (column-major 4x4), restarts accumulation
     def set_camera_pose(self, location, rotation):
@@ -164,6 +173,13 @@ class HipRenderer:
         hits = np.zeros(len(o), dtype=HIT)
         self._check(self.lib.rt_trace_closest(self._ctx, len(o), ptr(o), ptr(d), ptr(hits)))
         return hits
+
+    def shade_vertices(self, bounce: int, vertices) -> np.ndarray:
+        """The shade stage on caller-supplied vertices (api.SHADE_VERTEX records) -> api.SHADE_RESULT records."""
+        v = np.ascontiguousarray(vertices, dtype=api.SHADE_VERTEX)
+        out = np.zeros(len(v), dtype=api.SHADE_RESULT)
+        self._check(self.lib.rt_shade_vertices(self._ctx, len(v), bounce, ptr(v), ptr(out)))
+        return out
 
     def trace_shadow(self, origins, directions, tmax) -> np.ndarray:
         o, d, t = _f32(origins, 3), _f32(directions, 3), _f32(tmax)

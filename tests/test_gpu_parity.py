@@ -288,6 +288,44 @@ def test_scene_reload_replaces_every_device_table(rt, oracle, scene_cache):
     r.destroy()
 
 
+def test_reload_without_skybox_restores_the_white_sky(rt, scene_cache):
+    """A scene reloaded into a context that held a cube map gets the default 1x1 white cube when it brings none
+    (the reference builds a new PathTracer from the new scene, renderer.rs:193-231; src/scene/mod.rs:49-65)."""
+    import dataclasses
+    from ray_tracer_amd.scene import Scene, default_material, look_at_camera
+    cam = look_at_camera(16, 12, (0, 0, 3), (0, 0, 0))
+    empty = Scene(triangles=np.zeros(0, rt.api.TRIANGLE), materials=default_material(1), camera=cam).finalize()
+    dark = dataclasses.replace(empty, skybox=np.full((6, 2, 2, 4), 10, np.uint8))
+    r = rt.HipRenderer.create(dark, max_bounces=2)
+    assert r.render_radiance(0).max() < 0.01              # every ray misses: the dark cube map
+    r.upload_scene(empty)
+    assert np.array_equal(r.render_radiance(0), np.ones((12, 16, 3), np.float32))
+    r.upload_scene(dark)
+    assert r.render_radiance(0).max() < 0.01
+    r.destroy()
+
+
+def test_reload_scene_keeps_the_viewer_in_place(rt, scene_cache):
+    """reload_scene carries the current camera location and rotation over to the new scene (renderer.rs:194-196);
+    upload_scene installs the scene's own camera."""
+    import dataclasses
+    sc = scene_cache("cornell", width=64, height=64)
+    r = rt.HipRenderer.create(sc, max_bounces=2)
+    moved = sc.camera.copy()
+    moved["location"][0][:3] = (0.3, 1.1, 5.0)
+    r.set_camera(moved)
+    r.scene = dataclasses.replace(sc, camera=moved)
+    want_o, want_d, _ = r.generate_rays(0)
+    r.reload_scene(dataclasses.replace(sc))               # the new scene brings the original camera
+    o, d, _ = r.generate_rays(0)
+    assert np.array_equal(o, want_o) and np.array_equal(d, want_d)
+    assert r.sample_count() == 0
+    r.upload_scene(sc)
+    o, _, _ = r.generate_rays(0)
+    assert not np.array_equal(o, want_o)
+    r.destroy()
+
+
 def test_extend_empty_scene_and_ragged_sizes(rt):
     from ray_tracer_amd.scene import Scene, default_material, look_at_camera
     cam = look_at_camera(37, 23, (0, 0, 3), (0, 0, 0))
@@ -480,26 +518,8 @@ def test_absorption_fix_switch(rt, oracle, scene_cache):
 def test_large_material_and_light_tables_use_the_global_memory_path(rt, oracle):
     """More than 128 materials / 256 emissive triangles: shading reads its tables from global memory instead of the LDS
     copies, and a glass material forces closest-hit (not first-hit) shadow rays. Same parity bar as everywhere else."""
-    from ray_tracer_amd.scenes import Mesh
-    from ray_tracer_amd.scene import Scene, default_material, look_at_camera
-    rng = np.random.default_rng(31)
-    n_mat = 400
-    mats = default_material(n_mat)
-    mats["base_colour"][:, :3] = rng.uniform(0.2, 0.9, size=(n_mat, 3))
-    mats["roughness"] = rng.uniform(0.2, 1.0, size=n_mat)
-    mats["spec_trans"][5] = 1.0
-    mats["emission"][200:, :3] = rng.uniform(2.0, 6.0, size=(200, 1))
-    mesh = Mesh()
-    mesh.quad([[-6, 0, 6], [6, 0, 6], [6, 0, -6], [-6, 0, -6]], 0)
-    for k in range(320):   # 320 small emissive quads facing down = 640 emissive triangles
-        x, z = rng.uniform(-4, 4, size=2)
-        mesh.quad([[x - 0.1, 3.0, z - 0.1], [x + 0.1, 3.0, z - 0.1], [x + 0.1, 3.0, z + 0.1], [x - 0.1, 3.0, z + 0.1]], 200 + (k % 200))
-    for k in range(150):
-        c = rng.uniform([-4, 0.3, -4], [4, 2.0, 4])
-        mesh.box(c - 0.25, c + 0.25, 1 + (k % 199))
-    cam = look_at_camera(80, 48, (0.0, 2.0, 7.5), (0.0, 1.0, 0.0))
-    sc = Scene(triangles=mesh.triangles(), materials=mats, camera=cam).finalize()
-    assert len(sc.emissive_tris) == 640 and len(sc.materials) == 400
+    from util import big_tables_scene
+    sc = big_tables_scene()
     r = rt.HipRenderer.create(sc, max_bounces=5)
     o = oracle.OracleScene(sc)
     g = r.render_radiance(2)

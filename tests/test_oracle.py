@@ -302,3 +302,36 @@ def test_tonemap_known_points(oracle):
     assert out[2][0] == 255 and out[1][0] > out[3][0] > 0
     # greys stay grey under the saturation boost
     assert out[3][0] == out[3][1] == out[3][2]
+
+
+@pytest.mark.parametrize("name,kw,bounces", [("cornell", {"width": 48, "height": 48}, 5), ("glass_blob", {"scale": 0.02, "width": 48, "height": 27}, 6)])
+def test_vertex_twin_reassembles_the_whole_path(oracle, scene_cache, name, kw, bounces):
+    """The per-vertex entry points used to check the shade kernel (path_states -> shade_vertices, plus the shadow test)
+    are the same code ray_color runs: stitching them back together bounce by bounce gives render_radiance bit for bit."""
+    sc = scene_cache(name, **kw)
+    o = oracle.OracleScene(sc)
+    frame = 2
+    want, _ = o.render_radiance(frame, bounces)
+    want = want.reshape(-1, 3)
+    rad = np.zeros_like(want)
+    for b in range(bounces):
+        v, reached = o.path_states(frame, bounces, b)
+        if not reached.any():
+            break
+        idx = np.flatnonzero(reached)
+        res = o.shade_vertices(b, v[idx])
+        rad[idx] += res["emitted"]
+        hit = v[idx]["hit"]["prim"] != 0xFFFFFFFF
+        traced = res["has_shadow"] == 1
+        vis = np.zeros(len(idx), bool)
+        if traced.any():
+            vis[traced] = o.trace_shadow(res["shadow_o"][traced], res["shadow_d"][traced], res["shadow_tmax"][traced]) == 1
+        add = np.where((traced & vis)[:, None], res["shadow_contrib"], np.float32(0.0)).astype(np.float32)
+        rad[idx[hit]] += add[hit]
+        # a path recorded at vertex b+1 is exactly one the twin reports as continuing
+        if b + 1 < bounces:
+            _, nxt = o.path_states(frame, bounces, b + 1)
+            assert np.array_equal(np.flatnonzero(nxt), idx[res["alive"] == 1])
+    fin = np.isfinite(want).all(axis=1)
+    assert fin.mean() > 0.99
+    assert np.array_equal(rad[fin], want[fin])

@@ -1,0 +1,201 @@
+"""Stage-level parity of the shade kernel: everything ray_color does at one path vertex (main.comp:137-209;
+DirectLight disney.comp:623-720; MeshLightPdf disney.comp:297-330; DisneySample disney.comp:476-558), on identical
+inputs, vertex by vertex, against the CPU oracle's statement of the same vertex.
+
+Inputs are the oracle's own path states on arrival at vertex `bounce` (ray, closest hit, throughput, carried pdf, RNG
+state), so no upstream difference reaches the comparison. Bars:
+  * RNG state, light index, emissive-table entry and lobe: exact (they depend on +,-,*,/ and sqrt only);
+  * continuation / light-sample flags: exact except where a number computed through sin/cos/log/exp/pow lands within
+    rounding distance of the threshold it is compared with; every such vertex is audited;
+  * every float (emission, absorption, throughput, pdfs, next ray, shadow ray, contribution): 1e-5 relative, widened per
+    vertex only by that vertex's measured conditioning (how far the oracle's own result moves when its sin/cos/log/exp/pow
+    are nudged by 2 ulp), never by a blanket quota of outliers.
+"""
+import numpy as np
+import pytest
+
+from util import big_tables_scene, pcg_float_of_state, rel_close
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    ("cornell", {"width": 64, "height": 64}),
+    ("atrium", {"scale": 0.05, "width": 96, "height": 54}),
+    ("glass_blob", {"scale": 0.05, "width": 96, "height": 54}),
+    ("car", {"scale": 0.03, "width": 96, "height": 54}),
+    ("interior", {"scale": 0.01, "width": 96, "height": 54}),
+    ("big_tables", {}),
+]
+MAX_BOUNCES = 8
+RTOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def staged(rt, oracle, scene_cache):
+    made = {}
+
+    def get(name, kw):
+        key = (name, tuple(sorted(kw.items())))
+        if key not in made:
+            sc = big_tables_scene() if name == "big_tables" else scene_cache(name, **kw)
+            made[key] = (rt.HipRenderer.create(sc, max_bounces=MAX_BOUNCES), oracle.OracleScene(sc), sc)
+        return made[key]
+    yield get
+    for r, _, _ in made.values():
+        r.destroy()
+
+
+def close(a, b, atol):
+    return rel_close(a, b, RTOL, atol)
+
+
+def libm_spread(oracle, o, bounce, v, h):
+    """Per vertex and field: how far the oracle's own result moves when sin / cos / {log, exp, pow} inside the shading code
+    are nudged by 2-3 ulp (eight sign patterns). This is the conditioning of the formulas at that vertex, measured."""
+    fields = ("pdf", "throughput", "next_d", "shadow_contrib", "bsdf_pdf_light", "medium_throughput")
+    spread = {f: np.zeros(h[f].shape, np.float64) for f in fields}
+    try:
+        for bias in ((2, 2, 2), (-2, -2, -2), (2, -2, 2), (-2, 2, -2), (3, 0, 0), (-3, 0, 0), (0, 3, 0), (0, -3, 0)):
+            oracle.set_libm_bias(*bias)
+            p = o.shade_vertices(bounce, v)
+            for f in fields:
+                d = np.abs(p[f].astype(np.float64) - h[f])
+                spread[f] = np.maximum(spread[f], np.where(np.isfinite(d), d, np.inf))
+    finally:
+        oracle.set_libm_bias(0, 0, 0)
+    return spread
+
+
+def audit_flips(bounce, g, h, bad):
+    """Every vertex whose continuation flag differs must be a roulette or pdf-sign decision taken within rounding distance
+    of its threshold. Returns the number of vertices that are NOT explained that way."""
+    unexplained = 0
+    for i in np.flatnonzero(bad):
+        dead, live = (g[i], h[i]) if h[i]["alive"] else (h[i], g[i])
+        # (a) the BSDF sample's pdf is on the edge of "> 0" (or not finite on one side)
+        if not (dead["pdf"] > 0) or not np.isfinite(dead["pdf"]):
+            if abs(float(live["pdf"])) < 1e-6 or not np.isfinite(live["pdf"]):
+                continue
+        # (b) Russian roulette: the draw is recovered from the RNG state the dead side left behind
+        if bounce > 2:
+            draw = float(pcg_float_of_state(np.array([dead["seed"]]))[0])
+            p = float(np.clip(np.max(dead["throughput"]), 0.05, 0.95))
+            if abs(draw - p) <= 4e-6 * max(p, 1e-3):
+                continue
+        unexplained += 1
+    return unexplained
+
+
+@pytest.mark.parametrize("bounce", [0, 1, 4])
+@pytest.mark.parametrize("name,kw", CASES)
+def test_shade_vertices_match_oracle(staged, oracle, name, kw, bounce):
+    r, o, sc = staged(name, kw)
+    v, reached = o.path_states(1, MAX_BOUNCES, bounce)
+    v = v[reached]
+    if len(v) < 50:
+        pytest.skip(f"only {len(v)} paths of {name} reach vertex {bounce}")
+    g = r.shade_vertices(bounce, v)
+    h = o.shade_vertices(bounce, v)
+    n = len(v)
+    hitm = v["hit"]["prim"] != 0xFFFFFFFF
+
+    # ---- discrete decisions that depend on exactly rounded arithmetic only
+    assert np.array_equal(g["light_index"], h["light_index"])
+    assert np.array_equal(g["light_tri"], h["light_tri"])
+    assert np.array_equal(g["lobe"], h["lobe"])
+
+    # ---- continuation flag + RNG state
+    alive_bad = g["alive"] != h["alive"]
+    seed_bad = g["seed"] != h["seed"]
+    assert alive_bad.mean() <= 0.001, f"{alive_bad.sum()} of {n} continuation flags differ"
+    assert audit_flips(bounce, g, h, alive_bad) == 0
+    # the RNG state can differ only where the pdf test flipped (one side drew the roulette number, the other did not)
+    assert not (seed_bad & ~alive_bad).any()
+
+    # ---- emission / sky, absorption, throughput, carried pdf
+    assert close(g["emitted"], h["emitted"], 1e-7).all(axis=1).all()
+    assert np.array_equal(g["roughness"][hitm], h["roughness"][hitm])
+    # absorption (main.comp:182-184) goes through log and exp: 1e-5 relative; vertices it does not touch keep their bits
+    absorbed = hitm & (h["medium_throughput"] != v["throughput"]).any(axis=1)
+    assert np.array_equal(g["medium_throughput"][hitm & ~absorbed], v["throughput"][hitm & ~absorbed])
+    assert close(g["medium_throughput"][absorbed], h["medium_throughput"][absorbed], 0.0).all()
+    same = ~alive_bad
+    sampled = hitm & same & np.isfinite(h["pdf"]) & (h["lobe"] >= 0)
+    # The sampled direction, its pdf and f are not uniformly well conditioned in binary32, in any implementation of these
+    # formulas: a GGX peak at roughness 0.001 turns one ulp of cos(phi) into tens of percent of D, a cosine sample at
+    # grazing angle loses L.z = sqrt(1 - x^2 - y^2) to cancellation, a lobe remap divides by a small lobe weight. GLSL
+    # leaves sin/cos/log/exp/pow accurate to a few ulp only, so two correct implementations differ there. Each vertex is
+    # therefore allowed 1e-5 PLUS its own measured conditioning: the spread of the oracle's result when those functions
+    # are nudged by 2-3 ulp in eight sign patterns. Nothing else is allowed, for any vertex.
+    spread = libm_spread(oracle, o, bounce, v, h)
+    def within(field, atol_floor):
+        err = np.abs(g[field].astype(np.float64) - h[field])
+        tol = RTOL * np.abs(h[field].astype(np.float64)) + 2.0 * spread[field] + atol_floor
+        return err <= tol
+    # One more term for the specular lobes' pdf, which the nudging cannot see because it is a quantisation, not a slope:
+    # D = a^2 / (pi t^2) with t = 1 + (a^2 - 1) N.H^2 >= a^2, and N.H^2 next to 1 moves in steps of 6e-8 (one ulp), so
+    # two evaluations that round N.H^2 to neighbouring floats differ by up to 2 * 1.2e-7 / a^2 relative in D at the peak
+    # (a = roughness of the sampled lobe; 6e-4 at a = 0.02, nothing worth mentioning from a = 0.2 up).
+    mat_of = sc.triangles["material_idx"][np.where(hitm, v["hit"]["prim"], 0)]
+    alpha = np.where(h["lobe"] == 3, sc.materials["clearcoat_roughness"][mat_of], h["roughness"]).astype(np.float64)
+    peak_step = np.where(h["lobe"] >= 1, 2.4e-7 / np.maximum(alpha, 1e-3) ** 2, 0.0) * np.abs(h["pdf"].astype(np.float64))
+    pdf_ok = within("pdf", 1e-12 + peak_step)
+    thr_ok = within("throughput", 1e-12).all(axis=1)
+    assert pdf_ok[sampled].all(), f"pdf: {(~pdf_ok[sampled]).sum()} of {sampled.sum()} outside 1e-5 + conditioning"
+    assert thr_ok[sampled].all(), f"throughput: {(~thr_ok[sampled]).sum()} of {sampled.sum()} outside 1e-5 + conditioning"
+    pdf_plain = rel_close(g["pdf"], h["pdf"], RTOL, 0.0)[sampled].mean()
+    thr_plain = rel_close(g["throughput"], h["throughput"], RTOL, 0.0).all(axis=1)[sampled].mean()
+
+    # ---- next ray (where both continue)
+    both = (g["alive"] == 1) & (h["alive"] == 1)
+    if both.any():
+        assert within("next_d", 1e-6)[both].all()                              # components of a unit vector
+        scale = np.abs(h["next_o"][both]).max(axis=1, keepdims=True)
+        assert close(g["next_o"][both], h["next_o"][both], 1e-6 * np.maximum(scale, 1.0)).all(axis=1).all()
+
+    # ---- light sample: the kernel queues a shadow ray only when its contribution can be non-zero
+    want = (h["has_shadow"] == 1) & ~((h["shadow_contrib"] == 0).all(axis=1))
+    sh_bad = (g["has_shadow"] == 1) != want
+    assert sh_bad.mean() <= 0.001, f"{sh_bad.sum()} of {n} light-sample flags differ"
+    for i in np.flatnonzero(sh_bad):      # a flag may flip only where the contribution underflows
+        big = max(np.abs(g[i]["shadow_contrib"]).max(), np.abs(h[i]["shadow_contrib"]).max())
+        assert big < 1e-30, (i, g[i]["shadow_contrib"], h[i]["shadow_contrib"])
+    sh = (g["has_shadow"] == 1) & want
+    if sh.any():
+        assert np.array_equal(g["shadow_o"][sh], h["shadow_o"][sh])             # pos + normal * 0.001: exact arithmetic
+        assert np.array_equal(g["shadow_d"][sh], h["shadow_d"][sh])
+        assert np.array_equal(g["shadow_tmax"][sh], h["shadow_tmax"][sh])
+        assert np.array_equal(g["light_pdf"][sh], h["light_pdf"][sh])           # selection x area pdf: +,-,*,/ and sqrt only
+        bp_ok = close(g["bsdf_pdf_light"][sh], h["bsdf_pdf_light"][sh], 1e-9)
+        c_ok = close(g["shadow_contrib"][sh], h["shadow_contrib"][sh], 1e-9 + 1e-6 * np.abs(h["shadow_contrib"][sh]).max(axis=1, keepdims=True)).all(axis=1)
+        # the light direction and the view vector are exact on both sides, so is the half vector: no ill-conditioned term
+        assert bp_ok.all() and c_ok.all(), ((~bp_ok).sum(), (~c_ok).sum(), sh.sum())
+    print(f"{name} bounce {bounce}: {n} vertices, {hitm.sum()} hits, {both.sum()} continue, {sh.sum()} light samples, "
+          f"{alive_bad.sum()} audited flips, {sh_bad.sum()} underflow flips, "
+          f"within plain 1e-5: pdf {pdf_plain:.4f}, throughput {thr_plain:.4f} of {sampled.sum()} sampled vertices")
+
+
+def test_last_bounce_draws_no_bsdf_sample(staged):
+    """At the last vertex of a path the shader's BSDF sample can no longer influence the picture; the kernel skips it.
+    Emission and the light sample are unaffected."""
+    r, o, _ = staged("cornell", {"width": 64, "height": 64})
+    v, reached = o.path_states(2, MAX_BOUNCES, MAX_BOUNCES - 1)
+    v = v[reached]
+    assert len(v) > 20
+    g = r.shade_vertices(MAX_BOUNCES - 1, v)
+    h = o.shade_vertices(MAX_BOUNCES - 1, v)
+    assert (g["alive"] == 0).all() and (g["lobe"] == -1).all()
+    assert close(g["emitted"], h["emitted"], 1e-7).all()
+    assert np.array_equal(g["light_index"], h["light_index"]) and np.array_equal(g["light_tri"], h["light_tri"])
+
+
+def test_shade_vertices_argument_checks(staged, rt):
+    r, o, _ = staged("cornell", {"width": 64, "height": 64})
+    v, reached = o.path_states(0, MAX_BOUNCES, 0)
+    assert len(r.shade_vertices(0, v[:0])) == 0
+    with pytest.raises(rt.api.RtError, match="below max_bounces"):
+        r.shade_vertices(MAX_BOUNCES, v[:4])
+    bad = v[:4].copy()
+    bad["hit"]["prim"][1] = 10_000_000
+    with pytest.raises(rt.api.RtError, match="triangle"):
+        r.shade_vertices(0, bad)

@@ -107,3 +107,37 @@ def two_leaf_scene(n_left=40, n_right=64, seed=3):
     sc.bvh = nodes
     sc.build_lights()
     return sc
+
+
+def big_tables_scene(width=80, height=48):
+    """400 materials (one glass) and 640 emissive triangles: more than the shade kernel stages in LDS, so it reads its
+    material / light tables from global memory, and the glass material forces closest-hit (not first-hit) shadow rays."""
+    from ray_tracer_amd.scenes import Mesh
+    rng = np.random.default_rng(31)
+    n_mat = 400
+    mats = default_material(n_mat)
+    mats["base_colour"][:, :3] = rng.uniform(0.2, 0.9, size=(n_mat, 3))
+    mats["roughness"] = rng.uniform(0.2, 1.0, size=n_mat)
+    mats["spec_trans"][5] = 1.0
+    mats["emission"][200:, :3] = rng.uniform(2.0, 6.0, size=(200, 1))
+    mesh = Mesh()
+    mesh.quad([[-6, 0, 6], [6, 0, 6], [6, 0, -6], [-6, 0, -6]], 0)
+    for k in range(320):   # 320 small emissive quads facing down = 640 emissive triangles
+        x, z = rng.uniform(-4, 4, size=2)
+        mesh.quad([[x - 0.1, 3.0, z - 0.1], [x + 0.1, 3.0, z - 0.1], [x + 0.1, 3.0, z + 0.1], [x - 0.1, 3.0, z + 0.1]], 200 + (k % 200))
+    for k in range(150):
+        c = rng.uniform([-4, 0.3, -4], [4, 2.0, 4])
+        mesh.box(c - 0.25, c + 0.25, 1 + (k % 199))
+    cam = look_at_camera(width, height, (0.0, 2.0, 7.5), (0.0, 1.0, 0.0))
+    sc = Scene(triangles=mesh.triangles(), materials=mats, camera=cam, name="big-tables").finalize()
+    assert len(sc.emissive_tris) == 640 and len(sc.materials) == 400
+    return sc
+
+
+def pcg_float_of_state(state):
+    """The random number the generator returned when it moved INTO `state` (random.comp:6-12): the output is a function
+    of the updated state only, so the last draw of a path can be recovered from the state it left behind."""
+    s = np.asarray(state, dtype=np.uint64) & np.uint64(0xFFFFFFFF)
+    w = ((s >> ((s >> np.uint64(28)) + np.uint64(4))) ^ s) & np.uint64(0xFFFFFFFF)
+    w = (w * np.uint64(277803737)) & np.uint64(0xFFFFFFFF)
+    return (w.astype(np.float32) / np.float32(4294967296.0)).astype(np.float32)
