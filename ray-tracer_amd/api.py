@@ -39,6 +39,7 @@ SHADE_RESULT = np.dtype([("emitted", "<f4", 3), ("seed", "<u4"), ("throughput", 
                          ("light_tri", "<i4"), ("light_pdf", "<f4"), ("bsdf_pdf_light", "<f4"), ("roughness", "<f4"),
                          ("medium_throughput", "<f4", 3), ("reserved", "<u4")])
 assert SHADE_VERTEX.itemsize == 64 and SHADE_RESULT.itemsize == 144
+RT_STATIC_MAX_RAYS = 1 << 18
 assert LIGHT.itemsize == 48 and EMISSIVE_TRI.itemsize == 16 and CAMERA.itemsize == 128 and HIT.itemsize == 16
 
 NO_TEXTURE = 0xFFFFFFFF
@@ -126,6 +127,7 @@ API = {
     "rt_get_counters": (_I, [_P, _P]),
     "rt_reset_counters": (_I, [_P]),
     "rt_trace_closest": (_I, [_P, _U32, _P, _P, _P]),
+    "rt_trace_closest_static": (_I, [_P, _U32, _P, _P, _P]),
     "rt_trace_shadow": (_I, [_P, _U32, _P, _P, _P, _P]),
     "rt_shade_vertices": (_I, [_P, _U32, _U32, _P, _P]),
     "rt_bench_trace": (_I, [_P, _U32, _P, _P, _I, _U32, _P]),

@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -86,8 +87,35 @@ struct Lane {
 
 }  // namespace
 
+// Fixed staging area of rt_trace_closest_static: [work cursor, 256 B][origins 3 x f32][directions 3 x f32][hits 16 B].
+// Host code never uses the array's name as an address: each device holds its own copy, whose address
+// hipGetSymbolAddress reports once per device (static_scratch_for) and which is kept in g_static_scratch.
+constexpr size_t kStaticCursorBytes = 256;
+constexpr size_t kStaticBytes = kStaticCursorBytes + size_t(RT_STATIC_MAX_RAYS) * (12 + 12 + 16);
+static __device__ __align__(256) unsigned char scratch[kStaticBytes];
+
+constexpr int kMaxDevices = 64;
+static std::mutex g_static_mutex;
+static unsigned char* g_static_scratch[kMaxDevices] = {};
+
+// Device address of `scratch` on the current device `device` (resolved on first use, under a lock).
+static hipError_t static_scratch_for(int device, unsigned char** out) {
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_static_mutex);
+    if (!g_static_scratch[device]) {
+        void* p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!p) return hipErrorInvalidSymbol;
+        g_static_scratch[device] = static_cast<unsigned char*>(p);
+    }
+    *out = g_static_scratch[device];
+    return hipSuccess;
+}
+
 struct rt_ctx {
     int device = 0;
+    unsigned char* static_scratch = nullptr;  // this device's copy of `scratch`
     hipStream_t stream = nullptr;
     std::string err;
     uint32_t W = 0, H = 0, npix = 0;
@@ -384,6 +412,9 @@ extern "C" int rt_create(const rt_config* cfg, rt_ctx** out) {
     if (uint64_t(cfg->width) * cfg->height > 0x7FFFFFFFull) { c->err = "resolution too large"; return bail(RT_ERR_UNSUPPORTED); }
     int rc;
     if ((rc = bind_device(c)) != RT_OK) return bail(rc);
+    if (hipError_t se = static_scratch_for(c->device, &c->static_scratch); se != hipSuccess) {
+        c->err = std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(se); return bail(RT_ERR_DEVICE);
+    }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) c->n_cu = std::max(1, prop.multiProcessorCount);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return bail(RT_ERR_DEVICE); }
@@ -797,6 +828,34 @@ extern "C" int rt_trace_closest(rt_ctx* c, uint32_t n, const float* origins, con
     int rc = trace_common(c, n, origins, directions, nullptr, 0, h);
     if (rc != RT_OK) return rc;
     std::memcpy(hits, h.data(), size_t(n) * sizeof(rt_hit));
+    return RT_OK;
+}
+
+extern "C" int rt_trace_closest_static(rt_ctx* c, uint32_t n, const float* origins, const float* directions, rt_hit* hits) {
+    if (!c) return RT_ERR_INVALID;
+    if (n && (!origins || !directions || !hits)) return fail(c, RT_ERR_INVALID, "rt_trace_closest_static: null argument");
+    if (n > RT_STATIC_MAX_RAYS)
+        return fail(c, RT_ERR_UNSUPPORTED, "rt_trace_closest_static: " + std::to_string(n) + " rays exceed RT_STATIC_MAX_RAYS (" +
+                                               std::to_string(RT_STATIC_MAX_RAYS) + "); split the call or use rt_trace_closest");
+    if (!c->have_scene) return fail(c, RT_ERR_NO_SCENE, "no scene uploaded");
+    int rc;
+    if ((rc = bind_device(c)) != RT_OK) return rc;
+    if (n == 0) return RT_OK;
+    // no hipMalloc / hipFree and no allocating container from here on: everything lives in this device's `scratch`
+    unsigned char* base = c->static_scratch;
+    uint32_t* cursor = reinterpret_cast<uint32_t*>(base);
+    float* d_o = reinterpret_cast<float*>(base + kStaticCursorBytes);
+    float* d_d = reinterpret_cast<float*>(base + kStaticCursorBytes + size_t(RT_STATIC_MAX_RAYS) * 12);
+    float4* d_h = reinterpret_cast<float4*>(base + kStaticCursorBytes + size_t(RT_STATIC_MAX_RAYS) * 24);
+    HIPCHK(c, hipMemsetAsync(cursor, 0, kStaticCursorBytes, c->stream));      // the array keeps the previous call's contents
+    HIPCHK(c, hipMemcpyAsync(d_o, origins, size_t(n) * 12, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_d, directions, size_t(n) * 12, hipMemcpyHostToDevice, c->stream));
+    const uint32_t grid = trace_grid_for(c, n, c->trace_blocks_per_cu);
+    if (c->flags & RT_COUNT_TRAVERSAL) hipLaunchKernelGGL(k_trace_packed<true>, dim3(grid), dim3(kTraceBlock), 0, c->stream, c->sd, d_o, d_d, n, d_h, RT_CURSOR(cursor), c->tstats());
+    else hipLaunchKernelGGL(k_trace_packed<false>, dim3(grid), dim3(kTraceBlock), 0, c->stream, c->sd, d_o, d_d, n, d_h, RT_CURSOR(cursor), c->tstats());
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(hits, d_h, size_t(n) * sizeof(rt_hit), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return RT_OK;
 }
 

@@ -1130,6 +1130,29 @@ __global__ __launch_bounds__(kTraceBlock, RT_TRACE_WAVES_PER_EU) void k_trace_ra
     else flush_counts<COUNT>(n_node, n_leaf, n_tri, &stats->extend_node_pops, &stats->extend_leaf_pops, &stats->extend_tri_tests);
 }
 
+// Rays as the C ABI hands them over (n x 3 packed floats), traced without repacking.
+struct PackedRayWork {
+    const float* __restrict__ o3;
+    const float* __restrict__ d3;
+    float4* __restrict__ hits;
+    RT_DEV void load(uint32_t i, f3& o, f3& d, float& tmax) const {
+        o = f3{o3[3 * size_t(i)], o3[3 * size_t(i) + 1], o3[3 * size_t(i) + 2]};
+        d = f3{d3[3 * size_t(i)], d3[3 * size_t(i) + 1], d3[3 * size_t(i) + 2]};
+        tmax = INFINITY;
+    }
+    RT_DEV void store(uint32_t i, const LaneRay& r) const { hits[i] = make_float4(r.t, r.u, r.v, __uint_as_float(r.prim)); }
+};
+
+template <bool COUNT>
+__global__ __launch_bounds__(kTraceBlock, RT_TRACE_WAVES_PER_EU) void k_trace_packed(SceneDev sc, const float* __restrict__ o3, const float* __restrict__ d3,
+                                                         uint32_t n, float4* __restrict__ hits, uint32_t* cursor, TraceStats* stats) {
+    RT_TRACE_LDS(false)
+    uint32_t n_node = 0, n_leaf = 0, n_tri = 0;
+    PackedRayWork work{o3, d3, hits};
+    trace_persistent<COUNT, false, false>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, (lds_u8*)s_owner + (threadIdx.x & ~63u), hot, n_node, n_leaf, n_tri);
+    flush_counts<COUNT>(n_node, n_leaf, n_tri, &stats->extend_node_pops, &stats->extend_leaf_pops, &stats->extend_tri_tests);
+}
+
 struct BsdfIo {
     const float4* mats;   // 6 x float4 per input
     const float* eta; const float* V; const float* N; const float* L; const float* r;

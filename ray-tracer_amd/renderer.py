@@ -174,6 +174,13 @@ class HipRenderer:
         self._check(self.lib.rt_trace_closest(self._ctx, len(o), ptr(o), ptr(d), ptr(hits)))
         return hits
 
+    def trace_closest_static(self, origins, directions) -> np.ndarray:
+        """rt_trace_closest without any device allocation (at most api.RT_STATIC_MAX_RAYS rays per call)."""
+        o, d = _f32(origins, 3), _f32(directions, 3)
+        hits = np.zeros(len(o), dtype=HIT)
+        self._check(self.lib.rt_trace_closest_static(self._ctx, len(o), ptr(o), ptr(d), ptr(hits)))
+        return hits
+
     def shade_vertices(self, bounce: int, vertices) -> np.ndarray:
         """The shade stage on caller-supplied vertices (api.SHADE_VERTEX records) -> api.SHADE_RESULT records."""
         v = np.ascontiguousarray(vertices, dtype=api.SHADE_VERTEX)
