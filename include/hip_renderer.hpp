@@ -102,7 +102,13 @@ public:
                               uint32_t(scene.triangles.size()), uint32_t(scene.lights.size()), uint32_t(scene.emissive_tris.size())), ctx_);
         check(rt_set_camera(ctx_, &scene.camera), ctx_);
     }
-    void reload_scene(const Scene& scene) { upload_scene(scene); }
+    // reload_scene (renderer.rs:193-231): the new scene is viewed from the current camera pose (location and rotation
+    // are carried over, renderer.rs:194-196).
+    void reload_scene(Scene scene, const rt_camera& current) {
+        for (int k = 0; k < 4; ++k) scene.camera.location[k] = current.location[k];
+        for (int k = 0; k < 16; ++k) scene.camera.rotation[k] = current.rotation[k];
+        upload_scene(scene);
+    }
     void upload_textures(const std::vector<rt_texture>& textures, const rt_texture* skybox) {
         check(rt_upload_textures(ctx_, textures.data(), uint32_t(textures.size()), skybox), ctx_);
     }

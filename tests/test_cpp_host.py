@@ -3,14 +3,27 @@ any host; creating a renderer either succeeds (GPU present) or throws the librar
 import subprocess
 from pathlib import Path
 
+import pytest
+
 ROOT = Path(__file__).resolve().parents[1]
 
 
-def test_cpp_facade_builds_and_runs(tmp_path, rt):
+def _build_and_run(tmp_path):
     exe = tmp_path / "host_smoke"
     libdir = ROOT / "ray-tracer_amd"
     subprocess.run(["g++", "-std=c++17", "-O1", "-I", str(ROOT / "include"), str(ROOT / "tests" / "cpp" / "host_smoke.cpp"),
                     "-L", str(libdir), "-l:librt_hip.so", f"-Wl,-rpath,{libdir}", "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "gpu render ok" in out.stdout or "no gpu" in out.stdout
+    return out.stdout
+
+
+def test_cpp_facade_builds_and_runs(tmp_path, rt):
+    out = _build_and_run(tmp_path)
+    assert "gpu render ok" in out or "no gpu" in out
+
+
+@pytest.mark.gpu
+def test_cpp_facade_renders_on_the_gpu(tmp_path, rt):
+    """On a GPU box the facade must really render (the 'no gpu' branch is not acceptable there)."""
+    assert "gpu render ok" in _build_and_run(tmp_path)

@@ -1,0 +1,106 @@
+"""The multi-GPU path of BASELINE configs[4], as far as one GPU allows: the product renderer (not the oracle) slices samples
+by global frame index, and the fp32 accumulation buffers are sum-reduced in place through the zero-copy torch view of the
+library's device buffer, with the same reduce_accumulators call bench.py uses."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rccl_worker(rank, port):
+    # torch first: its HIP runtime must be the one the process initialises (bench.py imports in the same order)
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    import ray_tracer_amd as rt
+    from ray_tracer_amd import scenes
+    from ray_tracer_amd.distributed import accumulator_tensor, frame_slice, reduce_accumulators
+    sc = scenes.cornell(128, 96).finalize()
+    r = rt.HipRenderer.create(sc, max_bounces=4)
+    r.set_frame_slice(*frame_slice(0, 1))
+    r.render(3)
+    before = r.read_sum()
+    assert before[..., 3].min() == 3 and before[..., :3].max() > 0
+    t = accumulator_tensor(r, torch.device("cuda", 0))
+    ptr, n_bytes = r.accum_device_buffer()
+    assert t.data_ptr() == ptr and t.numel() * 4 == n_bytes == 128 * 96 * 16 and t.dtype == torch.float32
+    assert np.array_equal(t.cpu().numpy().reshape(96, 128, 4), before)          # the view sees the library's data
+    reduce_accumulators(t)                                                       # RCCL all-reduce, in place
+    torch.cuda.synchronize()
+    assert np.array_equal(r.read_sum(), before)                                  # sum over one rank
+    t.mul_(2.0)                                                                  # writes through the view land in the library's buffer
+    torch.cuda.synchronize()
+    assert np.array_equal(r.read_sum(), before * 2.0)
+    r.destroy()
+    dist.destroy_process_group()
+
+
+def test_rccl_all_reduce_of_the_zero_copy_accumulator_view():
+    """World size 1 over the `nccl` backend (RCCL): the collective runs in place on the library's own device buffer, and
+    what rt_read_sum_f32 returns afterwards is the reduced buffer. Runs in a child process so that torch initialises the
+    GPU runtime before the render library does, as in bench.py."""
+    import torch.multiprocessing as mp
+    mp.spawn(_rccl_worker, args=(_free_port(),), nprocs=1, join=True)
+
+
+def _worker(rank, world, port, n_local, out_dir):
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    sys.path.insert(0, str(root))
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ray_tracer_amd as rt
+    from ray_tracer_amd import scenes
+    from ray_tracer_amd.distributed import accumulator_tensor, frame_slice, reduce_accumulators
+    sc = scenes.atrium(width=320, height=180, scale=0.05).finalize(spatial=True)
+    r = rt.HipRenderer.create(sc, max_bounces=8)          # both ranks share GPU 0 here; on a node each has its own
+    r.set_frame_slice(*frame_slice(rank, world))
+    r.render(n_local)
+    t = accumulator_tensor(r, torch.device("cuda", 0))    # zero-copy view of the library's sum buffer
+    staged = t.cpu()                                       # gloo reduces host tensors; RCCL reduces `t` itself
+    reduce_accumulators(staged)
+    t.copy_(staged)
+    torch.cuda.synchronize()
+    if rank == 0:
+        np.save(os.path.join(out_dir, "reduced.npy"), r.read_sum())
+    dist.barrier()
+    r.destroy()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_of_the_product_renderer_reduce_to_the_single_context_image(rt, tmp_path):
+    """Two processes, each a HipRenderer rendering its slice of the global frame indices; after the reduction rank 0's
+    accumulation buffer equals one context rendering all frames (fp32 summation order aside)."""
+    import torch.multiprocessing as mp
+    from ray_tracer_amd import scenes
+    world, n_local = 2, 3
+    mp.spawn(_worker, args=(world, _free_port(), n_local, str(tmp_path)), nprocs=world, join=True)
+    reduced = np.load(tmp_path / "reduced.npy")
+    sc = scenes.atrium(width=320, height=180, scale=0.05).finalize(spatial=True)
+    whole = rt.HipRenderer.create(sc, max_bounces=8)
+    whole.render(world * n_local)
+    ref = whole.read_sum()
+    whole.destroy()
+    assert (reduced[..., 3] == world * n_local).all()
+    np.testing.assert_allclose(reduced, ref, rtol=2e-6, atol=1e-6)
