@@ -388,10 +388,38 @@ def test_bsdf_eval_and_sample_within_1e5(pair, oracle, transmissive):
     oL, ofs, ops = oracle.sample_bsdf(mats, eta, V, N, rr)
     fin = np.isfinite(oL).all(axis=1) & np.isfinite(ops)
     assert np.array_equal(np.isfinite(gL).all(axis=1) & np.isfinite(gps), fin)
-    assert rel_close(gL[fin], oL[fin], 1e-5, 2e-6).all(axis=1).mean() > 0.999
-    big = fin & (ops > 1e-4)
-    assert rel_close(gps[big], ops[big], 1e-4, 1e-6).mean() > 0.995
-    assert rel_close(gfs[big], ofs[big], 1e-4, 1e-6).all(axis=1).mean() > 0.995
+    # DisneySample is not uniformly well conditioned in binary32 (GGX peak at small roughness, grazing cosine samples, lobe
+    # remaps that divide by a small lobe weight), and GLSL leaves sin/cos/log/pow accurate to a few ulp only. Every input is
+    # held to 1e-5 relative plus ITS OWN measured conditioning: how far the oracle's result moves when those functions are
+    # nudged by 2-3 ulp. No quota of outliers.
+    sL, sf, sp = np.zeros(oL.shape), np.zeros(ofs.shape), np.zeros(ops.shape)
+    try:
+        for bias in ((2, 2, 2), (-2, -2, -2), (2, -2, 2), (-2, 2, -2), (3, 0, 0), (-3, 0, 0), (0, 3, 0), (0, -3, 0)):
+            oracle.set_libm_bias(*bias)
+            pL, pf, pp = oracle.sample_bsdf(mats, eta, V, N, rr)
+            with np.errstate(invalid="ignore"):
+                for acc, a_, b_ in ((sL, pL, oL), (sf, pf, ofs), (sp, pp, ops)):
+                    d = np.abs(a_.astype(np.float64) - b_)
+                    np.maximum(acc, np.where(np.isfinite(d), d, np.inf), out=acc)
+    finally:
+        oracle.set_libm_bias(0, 0, 0)
+    # quantisation of N.H^2 at the GGX / GTR1 peak (steps of one ulp of 1): up to 2.4e-7 / a^2 relative in D
+    a_min = np.minimum(np.maximum(mats["roughness"], 1e-3), np.maximum(mats["clearcoat_roughness"], 1e-3)).astype(np.float64)
+    peak = 2.4e-7 / a_min ** 2
+    def ok(g_, o_, spread, extra_rel=0.0, floor=0.0):
+        err = np.abs(g_.astype(np.float64) - o_)
+        scale = np.abs(o_.astype(np.float64))
+        rel = 1e-5 + (extra_rel[:, None] if np.ndim(extra_rel) and o_.ndim == 2 else extra_rel)
+        return err <= rel * scale + 2.0 * spread + floor
+    okL = ok(gL[fin], oL[fin], sL[fin], floor=1e-6).all(axis=1)
+    okp = ok(gps[fin], ops[fin], sp[fin], extra_rel=peak[fin], floor=1e-12)
+    okf = ok(gfs[fin], ofs[fin], sf[fin], extra_rel=peak[fin], floor=1e-12).all(axis=1)
+    plain_p = rel_close(gps[fin], ops[fin], 1e-5, 0.0).mean()
+    plain_f = rel_close(gfs[fin], ofs[fin], 1e-5, 0.0).all(axis=1).mean()
+    print(f"sampled BSDF ({'transmissive' if transmissive else 'opaque'}): {fin.sum()} finite of {n}; within plain 1e-5: pdf {plain_p:.4f}, f {plain_f:.4f}")
+    assert okL.all(), f"L: {(~okL).sum()} outside 1e-5 + conditioning"
+    assert okp.all(), f"pdf: {(~okp).sum()} outside 1e-5 + conditioning"
+    assert okf.all(), f"f: {(~okf).sum()} outside 1e-5 + conditioning"
 
 
 def test_texture_and_cubemap_fetch_bit_exact(pair):
