@@ -1,0 +1,167 @@
+"""The Rust side of the boundary (integration/rust/src/hip/ffi.rs) against the C headers it binds (include/rt_api.h,
+include/rt_types.h): every prototype and every record, by name, order, arity, pointer constness and scalar width.
+No Rust toolchain is needed (there is none in the build image): both sides are parsed as text. The calls renderer.rs
+makes are checked against the extern block too (name and argument count)."""
+import re
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+RUST = ROOT / "integration" / "rust" / "src" / "hip"
+
+SCALARS = {"int": "i32", "int32_t": "i32", "uint32_t": "u32", "uint64_t": "u64", "float": "f32", "size_t": "usize",
+           "uint8_t": "u8", "char": "c_char", "void": "c_void"}
+
+
+def camel(name):
+    return "".join(p.capitalize() for p in name.split("_"))
+
+
+def c_base(ct):
+    return SCALARS.get(ct) or (camel(ct) if ct.startswith("rt_") else None)
+
+
+def strip_c_comments(s):
+    return re.sub(r"/\*.*?\*/", "", s, flags=re.S)
+
+
+def c_prototypes(text):
+    out = {}
+    for ret, name, args in re.findall(r"^\s*(const char\*|int|void|uint32_t)\s+(rt_\w+)\s*\((.*?)\);", text, flags=re.S | re.M):
+        params = []
+        args = " ".join(args.split())
+        if args != "void":
+            for a in args.split(","):
+                m = re.match(r"\s*(const )?(\w+)\s*(\*\*|\*)?\s*(\w+)(\[\d*\])?$", a.strip())
+                assert m, a
+                const, ct, star, pname, arr = m.groups()
+                base = c_base(ct)
+                assert base, ct
+                if star == "**":
+                    ty = f"*mut *mut {base}"
+                elif star or arr:
+                    ty = ("*const " if const else "*mut ") + base
+                else:
+                    ty = base
+                params.append((pname, ty))
+        out[name] = (params, {"int": "i32", "void": None, "uint32_t": "u32", "const char*": "*const c_char"}[ret])
+    return out
+
+
+def c_structs(text):
+    out = {}
+    for name, body in re.findall(r"typedef struct (\w+) \{(.*?)\} \w+;", text, flags=re.S):
+        fields = []
+        for decl in body.split(";"):
+            decl = " ".join(decl.split())
+            if not decl:
+                continue
+            m = re.match(r"(const )?(\w+)\s*(\*?)\s*(.*)", decl)
+            const, ct, star, rest = m.groups()
+            for item in rest.split(","):
+                am = re.match(r"\s*(\w+)((?:\[\d+\])*)", item)
+                dims = re.findall(r"\[(\d+)\]", am.group(2))
+                ty = c_base(ct)
+                if star:
+                    ty = ("*const " if const else "*mut ") + ty
+                for d in reversed(dims):
+                    ty = f"[{ty}; {d}]"
+                fields.append((am.group(1), ty))
+        out[camel(name)] = fields
+    return out
+
+
+def rust_items(text):
+    text = re.sub(r"//.*", "", text)
+    block = re.search(r'extern "C" \{(.*?)\n\}', text, flags=re.S).group(1)
+    fns = {}
+    for name, args, ret in re.findall(r"pub fn (\w+)\s*\((.*?)\)\s*(?:->\s*([^;]+))?;", block, flags=re.S):
+        params = []
+        for a in [x.strip() for x in " ".join(args.split()).split(",") if x.strip()]:
+            pname, ty = a.split(":", 1)
+            params.append((pname.strip(), " ".join(ty.split())))
+        fns[name] = (params, ret.strip() if ret else None)
+    structs = {}
+    for name, body in re.findall(r"#\[repr\(C\)\]\s*(?:#\[derive\([^)]*\)\]\s*)?pub struct (\w+) \{(.*?)\n\}", text, flags=re.S):
+        fields = []
+        for f in [x.strip() for x in body.split(",\n") if x.strip()]:
+            m = re.match(r"(?:pub )?(\w+):\s*(.+?),?$", f, flags=re.S)
+            fields.append((m.group(1), " ".join(m.group(2).split())))
+        structs[name] = fields
+    return fns, structs
+
+
+def test_extern_block_matches_the_header_prototype_for_prototype():
+    c = c_prototypes(strip_c_comments((ROOT / "include" / "rt_api.h").read_text()))
+    r, _ = rust_items((RUST / "ffi.rs").read_text())
+    assert len(c) >= 37
+    assert sorted(c) == sorted(r), (set(c) ^ set(r))
+    for name, (cparams, cret) in c.items():
+        rparams, rret = r[name]
+        assert len(cparams) == len(rparams), name
+        assert [t for _, t in cparams] == [t for _, t in rparams], (name, cparams, rparams)
+        assert [n for n, _ in cparams] == [n for n, _ in rparams], (name, "argument names")
+        assert cret == rret, (name, cret, rret)
+
+
+def test_repr_c_records_match_the_header_field_for_field():
+    c = {}
+    c.update(c_structs(strip_c_comments((ROOT / "include" / "rt_types.h").read_text())))
+    c.update(c_structs(strip_c_comments((ROOT / "include" / "rt_api.h").read_text())))
+    _, r = rust_items((RUST / "ffi.rs").read_text())
+    r.pop("RtCtx")
+    assert sorted(c) == sorted(r), (set(c) ^ set(r))
+    for name, cf in c.items():
+        rf = [(("type" if n == "type_" else n), t) for n, t in r[name]]
+        assert cf == rf, (name, cf, rf)
+
+
+def test_constants_match():
+    h = (ROOT / "include" / "rt_api.h").read_text()
+    rs = (RUST / "ffi.rs").read_text()
+    for name, val in re.findall(r"\b(RT_(?:OK|ERR_\w+))\s*=\s*(-?\d+)", h):
+        assert re.search(rf"pub const {name}: i32 = {val};", rs), name
+    for name, shift in re.findall(r"\b(RT_\w+)\s*=\s*1u << (\d+)", h):
+        assert re.search(rf"pub const {name}: u32 = 1 << {shift};", rs), name
+    m = re.search(r"#define RT_STATIC_MAX_RAYS \(1u << (\d+)\)", h)
+    assert re.search(rf"pub const RT_STATIC_MAX_RAYS: u32 = 1 << {m.group(1)};", rs)
+
+
+def test_renderer_calls_exist_with_the_right_argument_count():
+    fns, _ = rust_items((RUST / "ffi.rs").read_text())
+    src = re.sub(r"//.*", "", (RUST / "renderer.rs").read_text())
+    calls = re.findall(r"\b(rt_\w+)\s*\(", src)
+    assert len(set(calls)) >= 12
+    for name in set(calls):
+        assert name in fns, name
+    # argument counts: split the balanced argument list of every call at top-level commas
+    for m in re.finditer(r"\b(rt_\w+)\s*\(", src):
+        depth, i, args, cur = 1, m.end(), [], ""
+        while depth:
+            ch = src[i]
+            if ch in "([{":
+                depth += 1
+            elif ch in ")]}":
+                depth -= 1
+                if depth == 0:
+                    break
+            if ch == "," and depth == 1:
+                args.append(cur)
+                cur = ""
+            else:
+                cur += ch
+            i += 1
+        if cur.strip():
+            args.append(cur)
+        assert len(args) == len(fns[m.group(1)][0]), (m.group(1), len(args))
+
+
+def test_build_script_compiles_the_same_sources_as_the_python_build():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_rt_build", ROOT / "ray-tracer_amd" / "build.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rs = (ROOT / "integration" / "rust" / "build.rs").read_text()
+    for src in mod.SOURCES:
+        assert f'"{src.name}"' in rs, src.name
+    for flag in ("--offload-arch=gfx950", "-ffp-contract=off", "-shared", "-fPIC"):
+        assert flag in rs and flag in mod.FLAGS
