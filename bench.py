@@ -182,7 +182,7 @@ def main():
     if rank == 0 and not args.no_roofline:
         # one pass of the same size as the timed region's passes (the library splits a call evenly over its two lanes, at most
         # 32 frames of 1080p per pass), so these launches are the size of the ones the trace of the main run shows
-        lanes = int(os.environ.get("RT_HIP_LANES", "2"))
+        lanes = int(os.environ.get("RT_HIP_LANES", "1"))
         k = max(1, min(32, -(-args.steps // max(1, lanes))))
         rc = rt.HipRenderer.create(scene, max_bounces=args.bounces, device=local_rank, flags=api.RT_COUNT_TRAVERSAL,
                                    frames_per_pass=args.frames_per_pass)

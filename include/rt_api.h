@@ -44,11 +44,12 @@ enum {
     RT_FIX_ABSORPTION    = 1u << 2, /* Beer-Lambert with the physical sign instead of main.comp:182-184           */
     RT_COUNT_TRAVERSAL   = 1u << 3, /* count node pops / triangle tests (mesh_tests, intersects.comp:136,140)     */
     RT_KERNEL_TIMING     = 1u << 4, /* bracket every kernel launch with events (gpu_timer.rs:18-78 analogue)      */
-    RT_SINGLE_STREAM     = 1u << 5  /* trace one wavefront pass at a time on one stream. By default consecutive
-                                       passes run on two streams so that the ALU-bound traversal of one overlaps
-                                       the memory-bound shading of the other; accumulation order, and therefore
-                                       every output bit, is the same either way. Implied by RT_KERNEL_TIMING so
-                                       that per-kernel times are those of kernels running alone.                 */
+    RT_SINGLE_STREAM     = 1u << 5  /* never run two wavefront passes concurrently, whatever RT_HIP_LANES (environment,
+                                       read at rt_create) asks for. One pass at a time is the default; with
+                                       RT_HIP_LANES=2..4 consecutive passes alternate between that many streams.
+                                       Accumulation order, and therefore every output bit, is the same either way.
+                                       Implied by RT_KERNEL_TIMING so that per-kernel times are those of kernels
+                                       running alone.                                                            */
 };
 
 typedef struct rt_config {

@@ -5,12 +5,11 @@
 // device layout, the path-state and queue buffers, the fp32 accumulator and the HIP streams on which the
 // kernels of a render call are queued back to back (no host synchronisation inside rt_render).
 //
-// Stream plan: wavefront passes alternate between `lanes` (a stream plus a private set of path-state and
-// queue buffers each), so the traversal kernels of one pass, which are bound by vector-ALU issue, share the
-// machine with the shading kernels of the neighbouring pass, which are bound by HBM. Accumulation of every
-// pass is queued on the context's main stream in pass order (it waits on the pass's lane through an event, and
-// the lane's next pass waits until its radiance buffer has been consumed), so the floating-point summation
-// order does not depend on how the lanes interleave.
+// Stream plan: a wavefront pass runs on a `lane` (a stream plus a private set of path-state buffers). By default there
+// is one lane; with RT_HIP_LANES=n consecutive passes alternate between n lanes and overlap. Accumulation of every pass is
+// queued on the context's main stream in pass order (it waits on the pass's lane through an event, and the lane's next
+// pass waits until its radiance buffer has been consumed), so the floating-point summation order does not depend on how
+// the lanes interleave.
 
 #include <hip/hip_runtime.h>
 
@@ -69,18 +68,21 @@ struct Span { int stage; hipEvent_t a, b; };
 // One in-flight wavefront pass: its stream, path state, queues and counters.
 struct Lane {
     hipStream_t stream = nullptr;
-    DevBuf ray_o, ray_d, hit, thr, rad, q0, q1, sq_o, sq_d, sq_c, sq_q, stage_next, stage_shadow, counts;
+    // path state of the current and the next bounce (ping-pong, queue order), closest hits (queue order), light samples
+    // (their own queue order), per-slot radiance, counters
+    DevBuf st_o[2], st_d[2], st_t[2], hit, rad, sq_o, sq_d, sq_c, counts;
     hipEvent_t pass_done = nullptr, consumed = nullptr;
     bool busy = false;   // a pass was queued whose radiance the main stream has (or will have) consumed at `consumed`
 
-    PathDev pd() const { return PathDev{ray_o.as<float4>(), ray_d.as<float4>(), hit.as<float4>(), thr.as<float4>(), rad.as<float4>()}; }
-    ShadowQueue sq() const { return ShadowQueue{sq_o.as<float4>(), sq_d.as<float4>(), sq_c.as<float4>(), sq_q.as<uint32_t>()}; }
-    uint32_t* q_count() const { return counts.as<uint32_t>(); }
-    uint32_t* sh_count() const { return counts.as<uint32_t>() + (kMaxBounces + 1); }
+    PathDev state(int k) const { return PathDev{st_o[k].as<float4>(), st_d[k].as<float4>(), st_t[k].as<float4>()}; }
+    ShadowDev sq() const { return ShadowDev{sq_o.as<float4>(), sq_d.as<float4>(), sq_c.as<float4>()}; }
+    std::vector<DevBuf*> path_buffers() {
+        return {&st_o[0], &st_o[1], &st_d[0], &st_d[1], &st_t[0], &st_t[1], &hit, &rad, &sq_o, &sq_d, &sq_c};
+    }
     uint32_t* ext_cursor() const { return counts.as<uint32_t>() + 2 * (kMaxBounces + 1); }   // one work cursor per bounce
     uint32_t* con_cursor() const { return counts.as<uint32_t>() + 3 * (kMaxBounces + 1); }
     uint32_t* aux_cursor() const { return counts.as<uint32_t>() + 4 * (kMaxBounces + 1); }   // stage-level entry points
-    // per bounce: kQueueShards append counters for the next-bounce queue, then kQueueShards for the shadow queue
+    // per bounce: kQueueShards append counters for the next bounce's paths, then kQueueShards for the light samples
     uint32_t* shard_counts(uint32_t bounce) const { return counts.as<uint32_t>() + 4 * (kMaxBounces + 1) + 4 + bounce * 2 * kQueueShards; }
     static size_t counts_words() { return 4 * (kMaxBounces + 1) + 4 + size_t(kMaxBounces) * 2 * kQueueShards; }
 };
@@ -149,7 +151,6 @@ struct rt_ctx {
     rt_timings last{};
     bool timings_dirty = false;
 
-    PathDev pd() const { return lanes[0].pd(); }
     uint32_t* aux_cursor() const { return lanes[0].aux_cursor(); }
     TraceStats* tstats() const { return stats.as<TraceStats>(); }
 };
@@ -254,8 +255,7 @@ int alloc_paths(rt_ctx* c) {
         if (rc != RT_ERR_OOM || !automatic || limit <= 1 || c->fpp <= 1) return rc;
         for (uint32_t i = 0; i < c->n_lanes; ++i) {          // give back what the failed attempt got
             Lane& l = c->lanes[i];
-            for (DevBuf* b : {&l.ray_o, &l.ray_d, &l.hit, &l.thr, &l.rad, &l.q0, &l.q1, &l.sq_o, &l.sq_d, &l.sq_c, &l.sq_q, &l.stage_next, &l.stage_shadow})
-                b->release();
+            for (DevBuf* b : l.path_buffers()) b->release();
         }
         (void)hipGetLastError();
         limit = std::min(limit, c->fpp);
@@ -274,18 +274,12 @@ int alloc_paths_for(rt_ctx* c, uint32_t fpp_limit) {
     // work distribution adds whole chunk strides to 32-bit item indices: keep them clear of wrap-around
     if (slots > 0x7FFFFFFFull) return fail(c, RT_ERR_UNSUPPORTED, "resolution x frames_per_pass exceeds 2^31 path slots");
     c->slot_cap = uint32_t(slots);
-    size_t v4 = size_t(slots) * sizeof(float4);
-    // staging regions: shard k receives at most ceil(ceil(slots/256)/shards) block-iterations of 256 entries
+    // append regions: shard k receives at most ceil(ceil(slots/256)/shards) block-iterations of 256 records
     c->shard_cap = uint32_t(((slots + kBlock - 1) / kBlock + kQueueShards - 1) / kQueueShards) * kBlock;
+    const size_t v4 = size_t(c->shard_cap) * kQueueShards * sizeof(float4);      // >= slots records: holds bounce 0 as well
     for (uint32_t i = 0; i < c->n_lanes; ++i) {
         Lane& l = c->lanes[i];
-        HIPCHK(c, l.ray_o.ensure(v4)); HIPCHK(c, l.ray_d.ensure(v4)); HIPCHK(c, l.hit.ensure(v4));
-        HIPCHK(c, l.thr.ensure(v4));   HIPCHK(c, l.rad.ensure(v4));
-        HIPCHK(c, l.q0.ensure(size_t(slots) * 4)); HIPCHK(c, l.q1.ensure(size_t(slots) * 4));
-        HIPCHK(c, l.sq_o.ensure(v4)); HIPCHK(c, l.sq_d.ensure(v4)); HIPCHK(c, l.sq_c.ensure(v4));
-        HIPCHK(c, l.sq_q.ensure(size_t(slots) * 4));
-        HIPCHK(c, l.stage_next.ensure(size_t(c->shard_cap) * kQueueShards * 4));
-        HIPCHK(c, l.stage_shadow.ensure(size_t(c->shard_cap) * kQueueShards * 4));
+        for (DevBuf* b : l.path_buffers()) HIPCHK(c, b->ensure(v4));
         HIPCHK(c, l.counts.ensure(sizeof(uint32_t) * Lane::counts_words()));
         HIPCHK(c, hipMemsetAsync(l.counts.p, 0, l.counts.bytes, c->stream));
     }
@@ -317,44 +311,39 @@ void refresh_camera(rt_ctx* c) {
 int run_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t frames, uint32_t frame_first, uint32_t frame_stride, uint32_t* seeds_out) {
     const uint32_t n_slots = frames * c->npix;
     const bool count = (c->flags & RT_COUNT_TRAVERSAL) != 0;
-    PathDev pd = l.pd();
-    ShadowQueue sq = l.sq();
-    HIPCHK(c, hipMemsetAsync(l.counts.p, 0, Lane::counts_words() * 4, st));   // queue lengths, cursors, append counters
+    const PathDev state[2] = {l.state(0), l.state(1)};
+    ShadowDev sq = l.sq();
+    float4* hit = l.hit.as<float4>();
+    float4* rad = l.rad.as<float4>();
+    HIPCHK(c, hipMemsetAsync(l.counts.p, 0, Lane::counts_words() * 4, st));   // cursors and append counters
     {
         StageTimer tm(c, ST_RAYGEN, st);
-        hipLaunchKernelGGL(k_raygen, dim3(grid_for(c, n_slots, 8)), dim3(kBlock), 0, st, c->cam, pd, c->npix, n_slots,
+        hipLaunchKernelGGL(k_raygen, dim3(grid_for(c, n_slots, 8)), dim3(kBlock), 0, st, c->cam, state[0], rad, c->npix, n_slots,
                            frame_first, frame_stride, seeds_out);
     }
-    uint32_t* queues[2] = {l.q0.as<uint32_t>(), l.q1.as<uint32_t>()};
     const uint32_t trace_grid = trace_grid_for(c, n_slots, c->trace_blocks_per_cu);
     const uint32_t shade_grid = grid_for(c, n_slots, c->shade_blocks_per_cu);
     for (uint32_t b = 0; b < c->max_bounces; ++b) {
-        const uint32_t* in_q = b == 0 ? nullptr : queues[b & 1];
-        const uint32_t* in_n = b == 0 ? nullptr : l.q_count() + b;
+        // this bounce's paths: every slot at bounce 0, afterwards whatever the previous shade appended to its regions
+        const Regions rin = b == 0 ? Regions{nullptr, c->shard_cap, n_slots} : Regions{l.shard_counts(b - 1), c->shard_cap, 0u};
+        const PathDev in = state[b & 1], out = state[(b + 1) & 1];
         {
             StageTimer tm(c, ST_EXTEND, st);
-            if (count) hipLaunchKernelGGL(k_extend<true>, dim3(trace_grid), dim3(kTraceBlock), 0, st, c->sd, pd, in_q, in_n, n_slots, RT_CURSOR(l.ext_cursor() + b), c->tstats());
-            else hipLaunchKernelGGL(k_extend<false>, dim3(trace_grid), dim3(kTraceBlock), 0, st, c->sd, pd, in_q, in_n, n_slots, RT_CURSOR(l.ext_cursor() + b), c->tstats());
+            if (count) hipLaunchKernelGGL(k_extend<true>, dim3(trace_grid), dim3(kTraceBlock), 0, st, c->sd, in, hit, rin, RT_CURSOR(l.ext_cursor() + b), c->tstats());
+            else hipLaunchKernelGGL(k_extend<false>, dim3(trace_grid), dim3(kTraceBlock), 0, st, c->sd, in, hit, rin, RT_CURSOR(l.ext_cursor() + b), c->tstats());
         }
         {
             StageTimer tm(c, ST_SHADE, st);
-            ShadeParams sp{b, c->max_bounces, c->flags, in_q, in_n, n_slots, l.stage_next.as<uint32_t>(), l.shard_counts(b),
-                           l.stage_shadow.as<uint32_t>(), l.shard_counts(b) + kQueueShards, c->shard_cap};
-            if (c->sd.n_mat <= kLdsMats && c->sd.n_emissive <= kLdsLights) hipLaunchKernelGGL(k_shade<true>, dim3(shade_grid), dim3(kBlock), 0, st, c->sd, pd, sq, sp);
-            else hipLaunchKernelGGL(k_shade<false>, dim3(shade_grid), dim3(kBlock), 0, st, c->sd, pd, sq, sp);
-        }
-        {
-            StageTimer tm(c, ST_SHADE, st);
-            const uint32_t per_shard = 16;
-            hipLaunchKernelGGL(k_compact_queues, dim3(kQueueShards * per_shard), dim3(kBlock), 0, st, l.stage_next.as<uint32_t>(),
-                               l.shard_counts(b), queues[(b + 1) & 1], l.q_count() + b + 1, l.stage_shadow.as<uint32_t>(),
-                               l.shard_counts(b) + kQueueShards, l.sq_q.as<uint32_t>(), l.sh_count() + b, c->shard_cap, per_shard);
+            ShadeParams sp{b, c->max_bounces, c->flags, rin, hit, out, l.shard_counts(b), sq, l.shard_counts(b) + kQueueShards, c->shard_cap, rad, nullptr};
+            if (c->sd.n_mat <= kLdsMats && c->sd.n_emissive <= kLdsLights) hipLaunchKernelGGL((k_shade<true, false>), dim3(shade_grid), dim3(kBlock), 0, st, c->sd, in, sp);
+            else hipLaunchKernelGGL((k_shade<false, false>), dim3(shade_grid), dim3(kBlock), 0, st, c->sd, in, sp);
         }
         if (c->sd.n_light + c->sd.n_emissive != 0) {
             StageTimer tm(c, ST_CONNECT, st);
             const bool any = c->sd.has_glass == 0;
+            const Regions rsh{l.shard_counts(b) + kQueueShards, c->shard_cap, 0u};
             auto kern = count ? (any ? k_connect<true, true> : k_connect<true, false>) : (any ? k_connect<false, true> : k_connect<false, false>);
-            hipLaunchKernelGGL(kern, dim3(trace_grid), dim3(kTraceBlock), 0, st, c->sd, pd, sq, l.sh_count() + b, RT_CURSOR(l.con_cursor() + b), c->tstats());
+            hipLaunchKernelGGL(kern, dim3(trace_grid), dim3(kTraceBlock), 0, st, c->sd, sq, rad, rsh, RT_CURSOR(l.con_cursor() + b), c->tstats());
         }
     }
     HIPCHK(c, hipGetLastError());
@@ -363,7 +352,7 @@ int run_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t frames, uint32_t frame
 
 // Folds the pass's queue lengths into the work counters; runs on the stream that consumed the pass.
 int finish_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t n_slots) {
-    hipLaunchKernelGGL(k_finish_pass, dim3(1), dim3(64), 0, st, l.q_count(), l.sh_count(), l.ext_cursor(), kMaxBounces + 1, n_slots, c->tstats());
+    hipLaunchKernelGGL(k_finish_pass, dim3(1), dim3(64), 0, st, l.shard_counts(0), c->max_bounces, n_slots, c->tstats());
     HIPCHK(c, hipGetLastError());
     return RT_OK;
 }
@@ -418,12 +407,15 @@ extern "C" int rt_create(const rt_config* cfg, rt_ctx** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) c->n_cu = std::max(1, prop.multiProcessorCount);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return bail(RT_ERR_DEVICE); }
-    c->n_lanes = (c->flags & (RT_SINGLE_STREAM | RT_KERNEL_TIMING | RT_REF_RGBA8_ACCUM)) ? 1 : 2;
+    // One lane by default: with path state stored in queue order the kernels of one pass keep the machine busy on their
+    // own, and a second concurrent pass only evicts the first one's BVH lines from L2 / Infinity Cache (measured: 4583 vs
+    // 4446 Mrays/s). RT_HIP_LANES=2..4 still runs consecutive passes on several streams (bit-identical results).
+    c->n_lanes = 1;
     if (const char* env = std::getenv("RT_HIP_TRACE_BLOCKS")) c->trace_blocks_per_cu = uint32_t(std::max(1, std::atoi(env)));
     if (const char* env = std::getenv("RT_HIP_SHADE_BLOCKS")) c->shade_blocks_per_cu = uint32_t(std::max(1, std::atoi(env)));
     if (const char* env = std::getenv("RT_HIP_LANES")) {   // tuning aid: 1..4 concurrent passes
         int v = std::atoi(env);
-        if (v >= 1 && v <= int(kMaxLanes) && !(c->flags & RT_KERNEL_TIMING)) c->n_lanes = uint32_t(v);
+        if (v >= 1 && v <= int(kMaxLanes) && !(c->flags & (RT_SINGLE_STREAM | RT_KERNEL_TIMING | RT_REF_RGBA8_ACCUM))) c->n_lanes = uint32_t(v);
     }
     for (uint32_t i = 0; i < c->n_lanes; ++i) {
         Lane& l = c->lanes[i];
@@ -671,7 +663,7 @@ extern "C" int rt_render(rt_ctx* c, uint32_t n_samples) {
         HIPCHK(c, hipStreamWaitEvent(c->stream, l.pass_done, 0));
         {
             StageTimer tm(c, ST_ACCUM);
-            hipLaunchKernelGGL(k_accumulate, dim3(grid_for(c, c->npix, 8)), dim3(kBlock), 0, c->stream, l.pd(), c->sum.as<float4>(),
+            hipLaunchKernelGGL(k_accumulate, dim3(grid_for(c, c->npix, 8)), dim3(kBlock), 0, c->stream, l.rad.as<float4>(), c->sum.as<float4>(),
                                c->accum8.as<uint32_t>(), c->fb.as<uint32_t>(), c->npix, frames, frame_first, c->slice_stride,
                                (c->flags & RT_REF_RGBA8_ACCUM) ? 1u : 0u);
         }
@@ -919,11 +911,11 @@ extern "C" int rt_generate_rays(rt_ctx* c, uint32_t frame, float* origins, float
     if (!c->paths_ok) return fail(c, RT_ERR_OOM, "no path buffers: the last resize ran out of device memory");
     int rc;
     if ((rc = bind_device(c)) != RT_OK) return rc;
-    hipLaunchKernelGGL(k_raygen, dim3(grid_for(c, c->npix, 8)), dim3(kBlock), 0, c->stream, c->cam, c->pd(), c->npix, c->npix, frame, 1u,
-                       c->seeds.as<uint32_t>());
+    hipLaunchKernelGGL(k_raygen, dim3(grid_for(c, c->npix, 8)), dim3(kBlock), 0, c->stream, c->cam, c->lanes[0].state(0), c->lanes[0].rad.as<float4>(),
+                       c->npix, c->npix, frame, 1u, c->seeds.as<uint32_t>());
     HIPCHK(c, hipGetLastError());
-    if ((rc = download_vec3(c, c->lanes[0].ray_o.as<float4>(), c->npix, origins)) != RT_OK) return rc;
-    if ((rc = download_vec3(c, c->lanes[0].ray_d.as<float4>(), c->npix, directions)) != RT_OK) return rc;
+    if ((rc = download_vec3(c, c->lanes[0].st_o[0].as<float4>(), c->npix, origins)) != RT_OK) return rc;
+    if ((rc = download_vec3(c, c->lanes[0].st_d[0].as<float4>(), c->npix, directions)) != RT_OK) return rc;
     if (seeds) HIPCHK(c, hipMemcpy(seeds, c->seeds.p, size_t(c->npix) * 4, hipMemcpyDeviceToHost));
     return RT_OK;
 }
@@ -951,46 +943,43 @@ extern "C" int rt_shade_vertices(rt_ctx* c, uint32_t n, uint32_t bounce, const r
     int rc;
     if ((rc = bind_device(c)) != RT_OK) return rc;
     if (n == 0) return RT_OK;
-    // The vertices go into lane 0's path-state buffers, slot i = vertex i, exactly as raygen/extend would have left them
-    // (radiance zero, so what comes back is what this vertex added). The main stream is ordered behind every pass queued so far.
+    // The vertices go into lane 0's path-state buffers at queue positions 0 .. n-1 (slot i = vertex i, radiance zero, so
+    // what comes back is what this vertex added). The main stream is ordered behind every pass queued so far.
     Lane& l = c->lanes[0];
-    std::vector<float4> ro(n), rd(n), hit(n), thr(n), rad(n);
+    std::vector<float4> ro(n), rd(n), hit(n), thr(n);
     for (uint32_t i = 0; i < n; ++i) {
         const rt_shade_vertex& v = vin[i];
-        ro[i] = make_float4(v.ray_o[0], v.ray_o[1], v.ray_o[2], 0.0f);
-        rd[i] = make_float4(v.ray_d[0], v.ray_d[1], v.ray_d[2], 0.0f);
         uint32_t prim = v.hit.prim;
         if (prim != kNoPrim && prim >= c->sd.n_tri) return fail(c, RT_ERR_INVALID, "rt_shade_vertices: vertex " + std::to_string(i) + " names a triangle the scene does not have");
+        ro[i] = make_float4(v.ray_o[0], v.ray_o[1], v.ray_o[2], v.prev_pdf);
+        rd[i] = make_float4(v.ray_d[0], v.ray_d[1], v.ray_d[2], 0.0f);
+        std::memcpy(&rd[i].w, &v.seed, 4);
+        thr[i] = make_float4(v.throughput[0], v.throughput[1], v.throughput[2], 0.0f);
+        std::memcpy(&thr[i].w, &i, 4);
         hit[i] = make_float4(v.hit.t, v.hit.u, v.hit.v, 0.0f);
         std::memcpy(&hit[i].w, &prim, 4);
-        thr[i] = make_float4(v.throughput[0], v.throughput[1], v.throughput[2], v.prev_pdf);
-        rad[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        std::memcpy(&rad[i].w, &v.seed, 4);
     }
     const size_t bytes = size_t(n) * sizeof(float4);
     HIPCHK(c, c->probe.ensure(3 * bytes));
-    HIPCHK(c, hipMemcpyAsync(l.ray_o.p, ro.data(), bytes, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(l.ray_d.p, rd.data(), bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(l.st_o[0].p, ro.data(), bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(l.st_d[0].p, rd.data(), bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(l.st_t[0].p, thr.data(), bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(l.hit.p, hit.data(), bytes, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(l.thr.p, thr.data(), bytes, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(l.rad.p, rad.data(), bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(l.counts.p, 0, Lane::counts_words() * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(c->probe.p, 0, 3 * bytes, c->stream));
-    HIPCHK(c, hipMemsetAsync(l.sq_o.p, 0, bytes, c->stream));
-    HIPCHK(c, hipMemsetAsync(l.sq_d.p, 0, bytes, c->stream));
-    HIPCHK(c, hipMemsetAsync(l.sq_c.p, 0, bytes, c->stream));
+    for (DevBuf* b : {&l.rad, &l.st_o[1], &l.st_d[1], &l.st_t[1], &l.sq_o, &l.sq_d, &l.sq_c}) HIPCHK(c, hipMemsetAsync(b->p, 0, bytes, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));     // the host vectors above are pageable: do not let them go before the copies ran
-    ShadeParams sp{bounce, c->max_bounces, c->flags, nullptr, nullptr, n, l.stage_next.as<uint32_t>(), l.shard_counts(bounce),
-                   l.stage_shadow.as<uint32_t>(), l.shard_counts(bounce) + kQueueShards, c->shard_cap, c->probe.as<uint4>()};
+    ShadeParams sp{bounce, c->max_bounces, c->flags, Regions{nullptr, c->shard_cap, n}, l.hit.as<float4>(), l.state(1), l.shard_counts(bounce),
+                   l.sq(), l.shard_counts(bounce) + kQueueShards, c->shard_cap, l.rad.as<float4>(), c->probe.as<uint4>()};
     const uint32_t grid = grid_for(c, n, c->shade_blocks_per_cu);
-    if (c->sd.n_mat <= kLdsMats && c->sd.n_emissive <= kLdsLights) hipLaunchKernelGGL((k_shade<true, true>), dim3(grid), dim3(kBlock), 0, c->stream, c->sd, l.pd(), l.sq(), sp);
-    else hipLaunchKernelGGL((k_shade<false, true>), dim3(grid), dim3(kBlock), 0, c->stream, c->sd, l.pd(), l.sq(), sp);
+    if (c->sd.n_mat <= kLdsMats && c->sd.n_emissive <= kLdsLights) hipLaunchKernelGGL((k_shade<true, true>), dim3(grid), dim3(kBlock), 0, c->stream, c->sd, l.state(0), sp);
+    else hipLaunchKernelGGL((k_shade<false, true>), dim3(grid), dim3(kBlock), 0, c->stream, c->sd, l.state(0), sp);
     HIPCHK(c, hipGetLastError());
-    std::vector<float4> so(n), sdir(n), scon(n);
+    std::vector<float4> rad(n), so(n), sdir(n), scon(n);
     std::vector<uint4> pr(3 * size_t(n));
-    HIPCHK(c, hipMemcpyAsync(ro.data(), l.ray_o.p, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(rd.data(), l.ray_d.p, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(thr.data(), l.thr.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(ro.data(), l.st_o[1].p, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(rd.data(), l.st_d[1].p, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(thr.data(), l.st_t[1].p, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(rad.data(), l.rad.p, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(so.data(), l.sq_o.p, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(sdir.data(), l.sq_d.p, bytes, hipMemcpyDeviceToHost, c->stream));
@@ -1002,8 +991,8 @@ extern "C" int rt_shade_vertices(rt_ctx* c, uint32_t n, uint32_t bounce, const r
         std::memset(&o, 0, sizeof(o));
         const uint4 p0 = pr[3 * size_t(i)], p1 = pr[3 * size_t(i) + 1], p2 = pr[3 * size_t(i) + 2];
         o.emitted[0] = rad[i].x; o.emitted[1] = rad[i].y; o.emitted[2] = rad[i].z;
-        std::memcpy(&o.seed, &rad[i].w, 4);
-        o.throughput[0] = thr[i].x; o.throughput[1] = thr[i].y; o.throughput[2] = thr[i].z; o.pdf = thr[i].w;
+        std::memcpy(&o.seed, &rd[i].w, 4);
+        o.throughput[0] = thr[i].x; o.throughput[1] = thr[i].y; o.throughput[2] = thr[i].z; o.pdf = ro[i].w;
         o.alive = p0.x & 1u;
         o.has_shadow = (p0.x >> 1) & 1u;
         if (o.alive) {

@@ -1,10 +1,13 @@
 // Wavefront path-tracing kernels for gfx950 (MI355X): raygen, extend, shade, connect, accumulate.
 //
-// One work item = one path segment. Paths live in fixed "slots" (slot = frame_in_pass * n_pixels + pixel);
-// a stage processes a queue of slot indices and appends survivors to the next queue with a wave-level
-// ballot/popcount prefix and ONE atomic per wavefront. Queue lengths stay on the device: every kernel is a
-// fixed-size grid of persistent wavefronts that reads its work count from HBM, so a whole multi-bounce
-// sample is queued without a host round trip.
+// One work item = one path segment. A path owns a fixed "slot" (slot = frame_in_pass * n_pixels + pixel) only for its
+// radiance sum; everything else it carries (ray, throughput, pdf, RNG state, its slot number) travels with it in QUEUE
+// ORDER: shade reads the state of the paths of this bounce as dense records and writes the survivors' state as dense
+// records for the next bounce, at a position obtained with a wave-level ballot/popcount prefix and ONE atomic per
+// wavefront. The appends go to kQueueShards regions with a counter each (a single counter would serialise ~10^5 returning
+// atomics per sample); the next kernel walks the regions one after another, so no compaction pass is needed. Queue
+// lengths stay on the device: every kernel is a fixed-size grid of persistent wavefronts that reads its work counts
+// from HBM, so a whole multi-bounce sample is queued without a host round trip.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -45,7 +48,7 @@ constexpr uint32_t kTraceBlock = RT_TRACE_BLOCK;   // workgroup size of the trav
 #define RT_LEAF_BATCH 12
 #endif
 #ifndef RT_HOT_LDS
-#define RT_HOT_LDS 752
+#define RT_HOT_LDS 746
 #endif
 #ifndef RT_TRACE_WAVES_PER_EU
 #define RT_TRACE_WAVES_PER_EU 8
@@ -77,19 +80,29 @@ struct SceneDev {
     TexView tex;
 };
 
+constexpr uint32_t kQueueShards = 64;
+
+// State of the paths of one bounce, three 16-byte records per path, indexed by queue position.
 struct PathDev {
-    float4* __restrict__ ray_o;   // {origin, -}
-    float4* __restrict__ ray_d;   // {direction, -}
-    float4* __restrict__ hit;     // {t, u, v, prim bits}
-    float4* __restrict__ thr;     // {throughput rgb, pdf of the BSDF sample that produced the current ray}
-    float4* __restrict__ rad;     // {radiance rgb, RNG state bits}
+    float4* __restrict__ o;   // {ray origin, pdf of the BSDF sample that produced the ray}
+    float4* __restrict__ d;   // {ray direction, RNG state bits}
+    float4* __restrict__ t;   // {throughput rgb, slot bits}
 };
 
-struct ShadowQueue {              // light-sample rays, stored at the slot of the path that spawned them
-    float4* __restrict__ o;       // {origin, tmax}
-    float4* __restrict__ d;       // {direction, -}
-    float4* __restrict__ c;       // {contribution if unoccluded, -}
-    const uint32_t* __restrict__ queue;   // dense list of slots that have a pending light sample this bounce
+// Light samples of one bounce, indexed by their own queue position.
+struct ShadowDev {
+    float4* __restrict__ o;   // {origin, tmax}
+    float4* __restrict__ d;   // {direction, slot bits}
+    float4* __restrict__ c;   // {contribution if unoccluded, -}
+};
+
+// Where the items of a queue live: kQueueShards regions of `cap` records each, region k filled from its start with
+// counts[k] records; item number v (0 <= v < sum of counts) is the (v - prefix[k])-th record of the region k it falls
+// into. counts == nullptr describes the queue of bounce 0: n_imm items at positions 0 .. n_imm-1.
+struct Regions {
+    const uint32_t* __restrict__ counts;
+    uint32_t cap;
+    uint32_t n_imm;
 };
 
 struct TraceStats {               // all 64-bit, updated with one atomic per wavefront
@@ -118,6 +131,39 @@ RT_DEV uint32_t wave_sum(uint32_t v) {
     return v;  // valid in lane 0
 }
 
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+
+// Exclusive prefix of the region counts into s_prefix[0..64] (s_prefix[64] = number of items), by the first wavefront
+// of the workgroup; ends with a barrier. Returns the number of items.
+RT_DEV uint32_t load_region_prefix(const Regions& rg, uint32_t* s_prefix) {
+    if (threadIdx.x < 64) {
+        uint32_t c = rg.counts ? rg.counts[threadIdx.x] : (threadIdx.x == 0 ? rg.n_imm : 0u);
+        uint32_t incl = c;
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t up = __shfl_up(incl, off);
+            if (int(threadIdx.x) >= off) incl += up;
+        }
+        s_prefix[threadIdx.x + 1] = incl;
+        if (threadIdx.x == 0) s_prefix[0] = 0u;
+    }
+    __syncthreads();
+    return s_prefix[kQueueShards];
+}
+
+// Position of item v: which region it falls into (binary search over the 64 prefixes in LDS), then its offset there.
+struct RegionMap {
+    const lds_u32* prefix;
+    uint32_t cap;
+    bool identity;
+    RT_DEV uint32_t operator()(uint32_t v) const {
+        if (identity) return v;
+        uint32_t k = 0;
+        for (uint32_t step = kQueueShards >> 1; step != 0; step >>= 1)
+            if (prefix[k + step] <= v) k += step;
+        return k * cap + (v - prefix[k]);
+    }
+};
+
 // ---- traversal -----------------------------------------------------------------------------------------
 // Per ray, visit order and tie rules are exactly those of hit_meshes (intersects.comp:124-175): the nearer child
 // first, on equal entry distance the right child first, a child is entered only while its entry distance is
@@ -145,14 +191,12 @@ struct LaneRay {
     uint32_t cur;        // node record index, leaf reference, or kDone (lanes without a ray always hold kDone)
     uint32_t tos;        // top of the stack (kDone = stack empty)
     uint32_t sp;         // entries below the top; entry k (1-based) lives in memory slot k, slot 0 always reads kDone
-    uint32_t item;       // index of the work item this lane is tracing
+    uint32_t item;       // handle of the work item this lane is tracing (what Work::load returned)
 };
 
 // The LDS part of the stack is addressed through an explicit LDS pointer type so pushes and pops stay ds_write /
 // ds_read; with generic pointers the compiler folds the LDS and scratch cases into one flat access whose
 // completion every iteration then has to wait for.
-typedef __attribute__((address_space(3))) uint32_t lds_u32;
-
 // Memory slots of the stack: slot 0 is a permanent kDone (so popping an empty stack needs no test), slots
 // 1 .. kStackLds-1 are in LDS, higher ones in scratch.
 RT_DEV void slot_store(lds_u32* stack, uint32_t* spill, uint32_t slot, uint32_t v) {
@@ -440,9 +484,10 @@ RT_DEV void leaf_phase(const SceneDev& sc, LaneRay& r, unsigned long long parked
 }
 
 // Work description for the persistent tracer: how item i becomes a ray and where its result goes.
-//   bool load(uint32_t i, f3& o, f3& d, float& tmax)      -- tmax is the initial "closest so far"
+//   uint32_t load(uint32_t i, f3& o, f3& d, float& tmax)  -- tmax is the initial "closest so far"; returns a handle
+//                                                            (where the item lives) that store() gets back
 // ANYHIT turns the closest-hit search into an occlusion query (stop at the first hit below tmax).
-//   void store(uint32_t i, const LaneRay& r)
+//   void store(uint32_t handle, const LaneRay& r)
 // WIDE (occlusion queries only): walk the 4-wide tree (SceneDev::wide) instead of the binary one.
 template <bool COUNT, bool ANYHIT, bool WIDE, class Work>
 RT_DEV void trace_persistent(const SceneDev& sc, const Work& work, uint32_t n, uint32_t* cursor, lds_u32* stack, lds_u8* slot_owner,
@@ -500,10 +545,10 @@ RT_DEV void trace_persistent(const SceneDev& sc, const Work& work, uint32_t n, u
             if (!live && rank < avail) {
                 uint32_t mine = chunk_pos + rank;
                 float tmax;
-                work.load(mine, r.o, r.d, tmax);
+                r.item = work.load(mine, r.o, r.d, tmax);
                 r.inv = f3{1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z};
                 r.t = tmax; r.u = 0.0f; r.v = 0.0f; r.prim = kNoPrim;
-                r.item = mine; r.sp = 0; r.tos = kDone;
+                r.sp = 0; r.tos = kDone;
                 { const uint32_t root = WIDE ? sc.wide_root : sc.root_ref; r.cur = root == kRefNone ? kDone : root; }
                 live = true;
             }
@@ -552,7 +597,7 @@ RT_DEV void trace_persistent(const SceneDev& sc, const Work& work, uint32_t n, u
 // ---- kernels -------------------------------------------------------------------------------------------
 
 // Seed rule + thin-lens camera ray for every slot (main.comp:251; generate_ray.comp:2-29).
-__global__ __launch_bounds__(kBlock) void k_raygen(rt_camera cam, PathDev pd, uint32_t n_pixels, uint32_t n_slots,
+__global__ __launch_bounds__(kBlock) void k_raygen(rt_camera cam, PathDev pd, float4* __restrict__ rad, uint32_t n_pixels, uint32_t n_slots,
                                                    uint32_t frame_first, uint32_t frame_stride, uint32_t* seeds_out) {
     const uint32_t W = cam.resolution[0];
     const float* m = cam.rotation;
@@ -588,60 +633,63 @@ __global__ __launch_bounds__(kBlock) void k_raygen(rt_camera cam, PathDev pd, ui
         f3 ow = f3{m[0] * ap.x + m[4] * ap.y + m[8] * ap.z, m[1] * ap.x + m[5] * ap.y + m[9] * ap.z,
                    m[2] * ap.x + m[6] * ap.y + m[10] * ap.z} + f3{cam.location[0], cam.location[1], cam.location[2]};
         (void)pcg_next(seed);  // ray.time
-        pd.ray_o[slot] = make_float4(ow.x, ow.y, ow.z, 0.0f);
-        pd.ray_d[slot] = make_float4(dw.x, dw.y, dw.z, 0.0f);
-        pd.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-        pd.rad[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(seed));
+        pd.o[slot] = make_float4(ow.x, ow.y, ow.z, 0.0f);                      // queue position of bounce 0 = slot
+        pd.d[slot] = make_float4(dw.x, dw.y, dw.z, __uint_as_float(seed));
+        pd.t[slot] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(slot));
+        rad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (seeds_out) seeds_out[slot] = seed;
     }
 }
 
 // LDS of a traversal workgroup: the per-lane stack heads and the resident node records (filled before any ray is traced).
 #define RT_TRACE_LDS(use_wide)                                                                                   \
+    __shared__ uint32_t s_prefix[kQueueShards + 1];                                                               \
     __shared__ uint32_t s_stack[kStackLds * kTraceBlock];                                                         \
     __shared__ uint8_t s_owner[kTraceBlock];                                                                      \
     __shared__ v4f s_hot[kHotLds ? kHotLds * 4 : 1];                                                              \
     const HotNodes hot = (use_wide) ? HotNodes{(const lds_v4f*)s_hot, sc.n_hot_wide < kHotWide ? sc.n_hot_wide : kHotWide} \
                                     : HotNodes{(const lds_v4f*)s_hot, sc.n_hot < kHotLds ? sc.n_hot : kHotLds};   \
-    if (kHotLds) { if (use_wide) load_hot_wide(sc, s_hot, hot.n); else load_hot_nodes(sc, s_hot, hot.n); }
+    if (kHotLds) { if (use_wide) load_hot_wide(sc, s_hot, hot.n); else load_hot_nodes(sc, s_hot, hot.n); }                \
+    (void)s_prefix;
 
 struct ExtendWork {
     PathDev pd;
-    const uint32_t* __restrict__ queue;   // nullptr = identity (bounce 0)
-    RT_DEV void load(uint32_t i, f3& o, f3& d, float& tmax) const {
-        uint32_t slot = queue ? queue[i] : i;
-        o = xyz(pd.ray_o[slot]);
-        d = xyz(pd.ray_d[slot]);
+    float4* __restrict__ hit;     // {t, u, v, prim bits} per queue position
+    RegionMap map;
+    RT_DEV uint32_t load(uint32_t i, f3& o, f3& d, float& tmax) const {
+        const uint32_t p = map(i);
+        o = xyz(pd.o[p]);
+        d = xyz(pd.d[p]);
         tmax = INFINITY;
+        return p;
     }
-    RT_DEV void store(uint32_t i, const LaneRay& r) const {
-        uint32_t slot = queue ? queue[i] : i;
-        pd.hit[slot] = make_float4(r.t, r.u, r.v, __uint_as_float(r.prim));
-    }
+    RT_DEV void store(uint32_t p, const LaneRay& r) const { hit[p] = make_float4(r.t, r.u, r.v, __uint_as_float(r.prim)); }
 };
 
 // Occluded = a closest hit nearer than tmax whose material is not glass-like (disney.comp:697-701,
-// intersects.comp:152-154). Each slot owns at most one entry per bounce, so the add needs no atomic.
+// intersects.comp:152-154). A path has at most one light sample per bounce, so the add to its slot needs no atomic.
 struct ConnectWork {
     SceneDev sc;
-    PathDev pd;
-    ShadowQueue sq;
-    RT_DEV void load(uint32_t i, f3& o, f3& d, float& tmax) const {
-        uint32_t slot = sq.queue[i];
-        float4 o4 = sq.o[slot];
+    ShadowDev sq;
+    float4* __restrict__ rad;     // per slot {radiance rgb, -}
+    RegionMap map;
+    RT_DEV uint32_t load(uint32_t i, f3& o, f3& d, float& tmax) const {
+        const uint32_t p = map(i);
+        float4 o4 = sq.o[p];
         o = xyz(o4);
-        d = xyz(sq.d[slot]);
+        d = xyz(sq.d[p]);
         tmax = o4.w;
+        return p;
     }
-    RT_DEV void store(uint32_t i, const LaneRay& r) const {
+    RT_DEV void store(uint32_t p, const LaneRay& r) const {
         bool blocked = false;
         if (r.prim != kNoPrim) blocked = (__float_as_uint(sc.shade[size_t(r.prim) * 4].w) & 0x80000000u) == 0u;
         if (!blocked) {
-            uint32_t slot = sq.queue[i];
-            float4 c = sq.c[slot];
-            float4 a = pd.rad[slot];
+            const uint32_t slot = __float_as_uint(sq.d[p].w);
+            float4 c = sq.c[p];
+            float4 a = rad[slot];
             a.x += c.x; a.y += c.y; a.z += c.z;
-            pd.rad[slot] = a;
+            rad[slot] = a;
         }
     }
 };
@@ -658,15 +706,14 @@ RT_DEV void flush_counts(uint32_t n_node, uint32_t n_leaf, uint32_t n_tri, unsig
     }
 }
 
-// extend: closest hit for every queued slot (a persistent grid; `cursor` hands out queue entries).
+// extend: closest hit for every path of the bounce (a persistent grid; `cursor` hands out the tail of the queue).
 template <bool COUNT>
-__global__ __launch_bounds__(kTraceBlock, RT_TRACE_WAVES_PER_EU) void k_extend(SceneDev sc, PathDev pd, const uint32_t* __restrict__ queue,
-                                                   const uint32_t* __restrict__ count_ptr, uint32_t count_imm,
+__global__ __launch_bounds__(kTraceBlock, RT_TRACE_WAVES_PER_EU) void k_extend(SceneDev sc, PathDev pd, float4* __restrict__ hit, Regions rg,
                                                    uint32_t* cursor, TraceStats* stats) {
     RT_TRACE_LDS(false)
-    const uint32_t n = count_ptr ? *count_ptr : count_imm;
+    const uint32_t n = load_region_prefix(rg, s_prefix);
     uint32_t n_node = 0, n_leaf = 0, n_tri = 0;
-    ExtendWork work{pd, queue};
+    ExtendWork work{pd, hit, RegionMap{(const lds_u32*)s_prefix, rg.cap, rg.counts == nullptr}};
     trace_persistent<COUNT, false, false>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, (lds_u8*)s_owner + (threadIdx.x & ~63u), hot, n_node, n_leaf, n_tri);
     flush_counts<COUNT>(n_node, n_leaf, n_tri, &stats->extend_node_pops, &stats->extend_leaf_pops, &stats->extend_tri_tests);
 }
@@ -675,35 +722,33 @@ __global__ __launch_bounds__(kTraceBlock, RT_TRACE_WAVES_PER_EU) void k_extend(S
 // When no material of the scene is glass-like (spec_trans > 0.5) "the closest hit is opaque" is the same predicate as
 // "there is a hit", so the query stops at the first hit (ANYHIT); with glass present the closest hit decides.
 template <bool COUNT, bool ANYHIT>
-__global__ __launch_bounds__(kTraceBlock, RT_TRACE_WAVES_PER_EU) void k_connect(SceneDev sc, PathDev pd, ShadowQueue sq,
-                                                    const uint32_t* __restrict__ count_ptr, uint32_t* cursor, TraceStats* stats) {
+__global__ __launch_bounds__(kTraceBlock, RT_TRACE_WAVES_PER_EU) void k_connect(SceneDev sc, ShadowDev sq, float4* __restrict__ rad, Regions rg,
+                                                    uint32_t* cursor, TraceStats* stats) {
     RT_TRACE_LDS(ANYHIT)
-    const uint32_t n = *count_ptr;
+    const uint32_t n = load_region_prefix(rg, s_prefix);
     uint32_t n_node = 0, n_leaf = 0, n_tri = 0;
-    ConnectWork work{sc, pd, sq};
+    ConnectWork work{sc, sq, rad, RegionMap{(const lds_u32*)s_prefix, rg.cap, rg.counts == nullptr}};
     trace_persistent<COUNT, ANYHIT, ANYHIT>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, (lds_u8*)s_owner + (threadIdx.x & ~63u), hot, n_node, n_leaf, n_tri);
     flush_counts<COUNT>(n_node, n_leaf, n_tri, &stats->shadow_node_pops, &stats->shadow_leaf_pops, &stats->shadow_tri_tests);
 }
 
 struct ShadeParams {
     uint32_t bounce, max_bounces, flags;
-    const uint32_t* in_queue;      // nullptr = identity
-    const uint32_t* in_count_ptr;  // nullptr = use in_count_imm
-    uint32_t in_count_imm;
-    // Survivors and light samples are appended to kQueueShards staging regions of `shard_cap` entries each (region k takes
-    // the work of block-iterations k, k + kQueueShards, ...), each with its own counter: a single append counter would
-    // serialise ~10^5 returning atomics per sample on one word. k_compact_queues then packs the regions densely.
-    uint32_t* next_stage;
+    Regions in;                    // where this bounce's paths live in `pd_in` / `hit`
+    const float4* hit;             // {t, u, v, prim bits} per queue position, as extend left it
+    // Survivors and light samples are appended to kQueueShards regions of `shard_cap` records each (region k takes the work
+    // of block-iterations k, k + kQueueShards, ...), each with its own counter.
+    PathDev out;
     uint32_t* next_shard_counts;
-    uint32_t* shadow_stage;
+    ShadowDev shadow;
     uint32_t* shadow_shard_counts;
     uint32_t shard_cap;
-    // k_shade<.., true> only: three records per slot, {alive | queued light sample << 1, light index, lobe, light-table entry},
+    float4* rad;                   // per slot {radiance rgb, -}
+    // k_shade<.., true> only: outputs are written at the INPUT position instead of being appended, and three records per
+    // position report {alive | queued light sample << 1, light index, lobe, light-table entry},
     // {light pdf, BSDF pdf for the light direction, roughness used, -} and {throughput after absorption, -}
     uint4* probe;
 };
-
-constexpr uint32_t kQueueShards = 64;
 
 constexpr uint32_t kLdsMats = 128;     // materials staged in LDS by k_shade<true> (12 KiB)
 constexpr uint32_t kLdsLights = 256;   // emissive triangles (CDF + light table) staged in LDS by k_shade<true> (17 KiB)
@@ -715,7 +760,8 @@ constexpr uint32_t kLdsLights = 256;   // emissive triangles (CDF + light table)
 // PROBE: the same code additionally records the discrete decisions taken at each vertex (which light, which lobe) and the
 // two pdfs of the light sample, for the stage-level entry point that checks this kernel vertex by vertex.
 template <bool LDS_TABLES, bool PROBE = false>
-__global__ __launch_bounds__(kBlock, RT_SHADE_WAVES) void k_shade(SceneDev sc, PathDev pd, ShadowQueue sq, ShadeParams sp) {
+__global__ __launch_bounds__(kBlock, RT_SHADE_WAVES) void k_shade(SceneDev sc, PathDev pd, ShadeParams sp) {
+    __shared__ uint32_t s_prefix[kQueueShards + 1];
     __shared__ v4f s_mats[LDS_TABLES ? kLdsMats * 6 : 1];
     __shared__ v4f s_lt[LDS_TABLES ? kLdsLights * 4 : 1];
     __shared__ float s_cdf[LDS_TABLES ? kLdsLights : 1];
@@ -732,7 +778,8 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_WAVES) void k_shade(SceneDev sc, P
     const lds_v4f* l_mats = (const lds_v4f*)s_mats;
     const lds_v4f* l_lt = (const lds_v4f*)s_lt;
     const lds_f32* l_cdf = (const lds_f32*)s_cdf;
-    const uint32_t n = sp.in_count_ptr ? *sp.in_count_ptr : sp.in_count_imm;
+    const uint32_t n = load_region_prefix(sp.in, s_prefix);      // ends with a barrier: the tables above are complete too
+    const RegionMap map{(const lds_u32*)s_prefix, sp.in.cap, sp.in.counts == nullptr};
     const uint32_t wave_base0 = (blockIdx.x * kBlock + threadIdx.x) & ~63u;
     const uint32_t stride = gridDim.x * kBlock;
     const int num_lights = int(sc.n_light + sc.n_emissive);
@@ -740,21 +787,25 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_WAVES) void k_shade(SceneDev sc, P
         const uint32_t i = base + lane_id();
         const bool valid = i < n;
         bool alive = false, want_shadow = false;
-        uint32_t slot = 0;
+        uint32_t slot = 0, pin = 0, seed = 0;
         float4 sh_o = {}, sh_d = {}, sh_c = {};
+        f3 next_o = {}, next_d = {}, next_thr = {};
+        float next_pdf = 0.0f;
         int probe_light = -1, probe_lobe = -1, probe_tri = -1;
         float probe_lpdf = 0.0f, probe_bpdf = 0.0f, probe_rough = 0.0f;
         f3 probe_thr = {0.0f, 0.0f, 0.0f};
         if (valid) {
-            slot = sp.in_queue ? sp.in_queue[i] : i;
-            float4 h4 = pd.hit[slot], o4 = pd.ray_o[slot], d4 = pd.ray_d[slot], T4 = pd.thr[slot], R4 = pd.rad[slot];
-            f3 ro = xyz(o4), rd = xyz(d4), thr = xyz(T4), rad = xyz(R4);
-            float prev_pdf = T4.w;
-            uint32_t seed = __float_as_uint(R4.w);
+            pin = map(i);
+            float4 h4 = sp.hit[pin], o4 = pd.o[pin], d4 = pd.d[pin], T4 = pd.t[pin];
+            f3 ro = xyz(o4), rd = xyz(d4), thr = xyz(T4);
+            f3 rad = {0.0f, 0.0f, 0.0f};                   // what this vertex adds to the path's radiance
+            float prev_pdf = o4.w;
+            seed = __float_as_uint(d4.w);
+            slot = __float_as_uint(T4.w);
             uint32_t prim = __float_as_uint(h4.w);
             if (prim == kNoPrim) {
                 f4 bg = sample_cube(sc.tex, rd, l_srgb);                          // main.comp:137-140
-                rad = rad + f3{bg.x, bg.y, bg.z} * thr;
+                rad = f3{bg.x, bg.y, bg.z} * thr;
             } else {
                 const float t = h4.x, u = h4.y, v = h4.z, w = 1.0f - h4.y - h4.z;
                 // The kernel is bound by the rate at which scattered 16-byte loads return, so a vertex fetches only what
@@ -829,7 +880,7 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_WAVES) void k_shade(SceneDev sc, P
                         }
                     }
                 }
-                rad = rad + mis * m.emission * thr;
+                rad = mis * m.emission * thr;
 
                 // "absorption" inside a transmissive medium, main.comp:182-184 (sign as upstream unless fixed)
                 if (dot(normal, ffn) < 0.0f && m.spec_trans > 0.0f) {
@@ -932,7 +983,7 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_WAVES) void k_shade(SceneDev sc, P
                     f3 L;
                     float pdf;
                     f3 f = disney_sample(m, pt, r1, r2, L, pdf, PROBE ? &probe_lobe : nullptr);
-                    if (PROBE) { pd.thr[slot] = make_float4(thr.x, thr.y, thr.z, pdf); }   // a path that ends here still reports its state
+                    if (PROBE) { next_thr = thr; next_pdf = pdf; }                         // a path that ends here still reports its state
                     if (pdf > 0.0f) {
                         thr = thr * (f / pdf);
                         bool go = true;
@@ -941,29 +992,44 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_WAVES) void k_shade(SceneDev sc, P
                             if (pcg_next(seed) > p) go = false;
                             else thr = thr / p;
                         }
-                        if (PROBE) pd.thr[slot] = make_float4(thr.x, thr.y, thr.z, pdf);
+                        if (PROBE) next_thr = thr;
                         if (go) {
                             alive = true;
-                            f3 no = pos + L * kRayEps;
-                            pd.ray_o[slot] = make_float4(no.x, no.y, no.z, 0.0f);
-                            pd.ray_d[slot] = make_float4(L.x, L.y, L.z, 0.0f);
-                            pd.thr[slot] = make_float4(thr.x, thr.y, thr.z, pdf);
+                            next_o = pos + L * kRayEps;
+                            next_d = L;
+                            next_thr = thr;
+                            next_pdf = pdf;
                         }
                     }
                 }
             }
-            pd.rad[slot] = make_float4(rad.x, rad.y, rad.z, __uint_as_float(seed));
+            // The slot's radiance is touched only by vertices that add something (sky on a miss, an emitter that was hit);
+            // a NaN term (0 * infinite throughput) passes the test and poisons the sum exactly as in the shader.
+            if (!(rad.x == 0.0f && rad.y == 0.0f && rad.z == 0.0f)) {
+                float4 a = sp.rad[slot];
+                a.x += rad.x; a.y += rad.y; a.z += rad.z;
+                sp.rad[slot] = a;
+            }
         }
-        // queue append: one atomic per wavefront and queue, spread over kQueueShards counters
+        // queue append: one atomic per wavefront and queue, spread over kQueueShards counters; the records themselves go
+        // to the reserved position, so the next bounce reads them as a dense stream
         const uint32_t shard = (base / kBlock) & (kQueueShards - 1u);
         uint32_t dst = wave_append(alive, sp.next_shard_counts + shard);
-        if (alive) sp.next_stage[shard * sp.shard_cap + dst] = slot;
         uint32_t sdst = wave_append(want_shadow, sp.shadow_shard_counts + shard);
+        const uint32_t pout = PROBE ? pin : shard * sp.shard_cap + dst;
+        const uint32_t spos = PROBE ? pin : shard * sp.shard_cap + sdst;
+        if (alive || (PROBE && valid)) {
+            sp.out.o[pout] = make_float4(next_o.x, next_o.y, next_o.z, next_pdf);
+            sp.out.d[pout] = make_float4(next_d.x, next_d.y, next_d.z, __uint_as_float(seed));
+            sp.out.t[pout] = make_float4(next_thr.x, next_thr.y, next_thr.z, __uint_as_float(slot));
+        }
         if (want_shadow) {
-            sq.o[slot] = sh_o; sq.d[slot] = sh_d; sq.c[slot] = sh_c;
-            sp.shadow_stage[shard * sp.shard_cap + sdst] = slot;
+            sp.shadow.o[spos] = sh_o;
+            sp.shadow.d[spos] = make_float4(sh_d.x, sh_d.y, sh_d.z, __uint_as_float(slot));
+            sp.shadow.c[spos] = sh_c;
         }
         if (PROBE && valid) {
+            slot = pin;
             sp.probe[3 * size_t(slot)] = make_uint4((alive ? 1u : 0u) | (want_shadow ? 2u : 0u), uint32_t(probe_light), uint32_t(probe_lobe), uint32_t(probe_tri));
             sp.probe[3 * size_t(slot) + 1] = make_uint4(__float_as_uint(probe_lpdf), __float_as_uint(probe_bpdf), __float_as_uint(probe_rough), 0u);
             sp.probe[3 * size_t(slot) + 2] = make_uint4(__float_as_uint(probe_thr.x), __float_as_uint(probe_thr.y), __float_as_uint(probe_thr.z), 0u);
@@ -971,26 +1037,6 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_WAVES) void k_shade(SceneDev sc, P
     }
 }
 
-
-// Packs the kQueueShards staging regions of both queues into dense queues and publishes their lengths.
-// grid = kQueueShards * per_shard blocks; block (s, m) copies every per_shard-th 256-entry piece of region s.
-__global__ __launch_bounds__(kBlock) void k_compact_queues(const uint32_t* __restrict__ next_stage, const uint32_t* __restrict__ next_counts,
-                                                           uint32_t* __restrict__ next_queue, uint32_t* __restrict__ next_total,
-                                                           const uint32_t* __restrict__ shadow_stage, const uint32_t* __restrict__ shadow_counts,
-                                                           uint32_t* __restrict__ shadow_queue, uint32_t* __restrict__ shadow_total,
-                                                           uint32_t shard_cap, uint32_t per_shard) {
-    const uint32_t s = blockIdx.x / per_shard, m = blockIdx.x % per_shard;
-    for (int q = 0; q < 2; ++q) {
-        const uint32_t* stage = q ? shadow_stage : next_stage;
-        const uint32_t* counts = q ? shadow_counts : next_counts;
-        uint32_t* out = q ? shadow_queue : next_queue;
-        uint32_t prefix = 0;
-        for (uint32_t k = 0; k < s; ++k) prefix += counts[k];
-        const uint32_t cnt = counts[s];
-        for (uint32_t i = m * kBlock + threadIdx.x; i < cnt; i += per_shard * kBlock) out[prefix + i] = stage[size_t(s) * shard_cap + i];
-        if (s == kQueueShards - 1 && m == 0 && threadIdx.x == 0) *(q ? shadow_total : next_total) = prefix + cnt;
-    }
-}
 
 // ---- accumulate / display ------------------------------------------------------------------------------
 RT_DEV f3 suppress_fireflies(f3 c, float max_value) {  // main.comp:114-120
@@ -1023,7 +1069,7 @@ RT_DEV uint32_t pack_rgba8(float r, float g, float b, float a) {
 // Folds the finished samples of one pass into the accumulator, in frame order (main.comp:260-267).
 // HDR mode: fp32 RGBA sum with the sample count in alpha; a non-finite sample component contributes 0.
 // Legacy mode: the shader's running mean stored in 8-bit UNORM every frame, plus the tone-mapped framebuffer.
-__global__ __launch_bounds__(kBlock) void k_accumulate(PathDev pd, float4* __restrict__ sum, uint32_t* __restrict__ accum8,
+__global__ __launch_bounds__(kBlock) void k_accumulate(const float4* __restrict__ rad, float4* __restrict__ sum, uint32_t* __restrict__ accum8,
                                                        uint32_t* __restrict__ framebuffer, uint32_t n_pixels,
                                                        uint32_t frames_in_pass, uint32_t frame_first, uint32_t frame_stride,
                                                        uint32_t legacy8) {
@@ -1035,7 +1081,7 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(PathDev pd, float4* __res
             f3 fb = {0, 0, 0};
             float fa = 0.0f;
             for (uint32_t f = 0; f < frames_in_pass; ++f) {
-                float4 r = pd.rad[size_t(f) * n_pixels + p];
+                float4 r = rad[size_t(f) * n_pixels + p];
                 f3 c = suppress_fireflies(f3{r.x, r.y, r.z}, 5.0f);
                 float alpha = 1.0f / float(frame_first + f * frame_stride + 1u);
                 float nw[4] = {mixf(old[0], c.x, alpha), mixf(old[1], c.y, alpha), mixf(old[2], c.z, alpha), mixf(old[3], 1.0f, alpha)};
@@ -1050,7 +1096,7 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(PathDev pd, float4* __res
         } else {
             float4 s = sum[p];
             for (uint32_t f = 0; f < frames_in_pass; ++f) {
-                float4 r = pd.rad[size_t(f) * n_pixels + p];
+                float4 r = rad[size_t(f) * n_pixels + p];
                 f3 c = suppress_fireflies(f3{r.x, r.y, r.z}, 5.0f);
                 s.x += isfinite(c.x) ? c.x : 0.0f;
                 s.y += isfinite(c.y) ? c.y : 0.0f;
@@ -1080,14 +1126,18 @@ __global__ void k_add_sum(float4* __restrict__ sum, const float4* __restrict__ o
 }
 
 // End of a pass: fold the per-bounce queue lengths into the 64-bit totals (the counters are cleared by a memset
-// at the start of the next pass).
-__global__ void k_finish_pass(uint32_t* __restrict__ q_count, uint32_t* __restrict__ sh_count, uint32_t* __restrict__ cursors,
-                              uint32_t n_counts, uint32_t camera_rays, TraceStats* stats) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        unsigned long long e = camera_rays, s = 0;
-        for (uint32_t b = 1; b < n_counts; ++b) e += q_count[b];
-        for (uint32_t b = 0; b < n_counts; ++b) s += sh_count[b];
-        stats->extend_rays += e;
+// at the start of the next pass). `shard_counts` holds, per bounce, kQueueShards counters of the paths that continued
+// (= the rays extend traces in the next bounce) followed by kQueueShards counters of the light samples queued.
+__global__ void k_finish_pass(const uint32_t* __restrict__ shard_counts, uint32_t n_bounces, uint32_t camera_rays, TraceStats* stats) {
+    if (blockIdx.x != 0 || threadIdx.x >= kQueueShards) return;
+    unsigned long long e = 0, s = 0;
+    for (uint32_t b = 0; b < n_bounces; ++b) {
+        if (b + 1 < n_bounces) e += shard_counts[b * 2 * kQueueShards + threadIdx.x];      // survivors of the last bounce are never traced
+        s += shard_counts[b * 2 * kQueueShards + kQueueShards + threadIdx.x];
+    }
+    for (int off = 32; off > 0; off >>= 1) { e += __shfl_down(e, off); s += __shfl_down(s, off); }
+    if (threadIdx.x == 0) {
+        stats->extend_rays += e + camera_rays;
         stats->shadow_rays += s;
         stats->camera_rays += camera_rays;
     }
@@ -1100,11 +1150,12 @@ struct RayListWork {
     const float4* __restrict__ rd;
     float4* __restrict__ hits;
     int shadow;
-    RT_DEV void load(uint32_t i, f3& o, f3& d, float& tmax) const {
+    RT_DEV uint32_t load(uint32_t i, f3& o, f3& d, float& tmax) const {
         float4 o4 = ro[i];
         o = xyz(o4);
         d = xyz(rd[i]);
         tmax = shadow ? o4.w : INFINITY;
+        return i;
     }
     RT_DEV void store(uint32_t i, const LaneRay& r) const {
         if (shadow) {
@@ -1135,10 +1186,11 @@ struct PackedRayWork {
     const float* __restrict__ o3;
     const float* __restrict__ d3;
     float4* __restrict__ hits;
-    RT_DEV void load(uint32_t i, f3& o, f3& d, float& tmax) const {
+    RT_DEV uint32_t load(uint32_t i, f3& o, f3& d, float& tmax) const {
         o = f3{o3[3 * size_t(i)], o3[3 * size_t(i) + 1], o3[3 * size_t(i) + 2]};
         d = f3{d3[3 * size_t(i)], d3[3 * size_t(i) + 1], d3[3 * size_t(i) + 2]};
         tmax = INFINITY;
+        return i;
     }
     RT_DEV void store(uint32_t i, const LaneRay& r) const { hits[i] = make_float4(r.t, r.u, r.v, __uint_as_float(r.prim)); }
 };

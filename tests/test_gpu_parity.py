@@ -636,13 +636,15 @@ def test_full_size_determinism_and_pass_batching(rt, full_atrium):
     a.destroy(); b.destroy()
 
 
-def test_overlapped_passes_match_single_stream_bit_for_bit(rt, full_atrium):
-    """Passes alternate between two streams by default; their accumulation is ordered, so the sum buffer equals the
-    single-stream one exactly, whatever the split of samples over calls. The stage-level entry points share lane 0's
-    buffers and must not disturb, or be disturbed by, passes still in flight."""
+def test_overlapped_passes_match_single_stream_bit_for_bit(rt, full_atrium, monkeypatch):
+    """With RT_HIP_LANES=2 consecutive passes alternate between two streams; their accumulation is ordered, so the sum
+    buffer equals the single-stream one exactly, whatever the split of samples over calls. The stage-level entry points
+    share lane 0's buffers and must not disturb, or be disturbed by, passes still in flight."""
     from ray_tracer_amd import api
+    monkeypatch.setenv("RT_HIP_LANES", "2")
     one = rt.HipRenderer.create(full_atrium, max_bounces=8, frames_per_pass=2, flags=api.RT_SINGLE_STREAM)
     two = rt.HipRenderer.create(full_atrium, max_bounces=8, frames_per_pass=2)
+    monkeypatch.delenv("RT_HIP_LANES")
     one.render(7)
     for n in (1, 3, 2, 1):
         two.dispatch_compute(n)
