@@ -44,6 +44,13 @@ enum {
     RT_FIX_ABSORPTION    = 1u << 2, /* Beer-Lambert with the physical sign instead of main.comp:182-184           */
     RT_COUNT_TRAVERSAL   = 1u << 3, /* count node pops / triangle tests (mesh_tests, intersects.comp:136,140)     */
     RT_KERNEL_TIMING     = 1u << 4, /* bracket every kernel launch with events (gpu_timer.rs:18-78 analogue)      */
+    RT_EXACT_ORDER       = 1u << 6, /* closest-hit search exactly as hit_meshes does it (intersects.comp:124-175): the
+                                       binary tree, the shader's box arithmetic, visiting order and tie rules, so triangle
+                                       ids equal the shader's bit for bit. Without it (the default) rays walk a compressed
+                                       4-wide tree with conservative boxes, about 1.4x faster: distances and ids still
+                                       equal the shader's except where two triangles lie within rounding distance of
+                                       each other along the ray (either may be reported), or where the shader's own box
+                                       test loses a hit to rounding (the hit is then reported).                       */
     RT_SINGLE_STREAM     = 1u << 5  /* never run two wavefront passes concurrently, whatever RT_HIP_LANES (environment,
                                        read at rt_create) asks for. One pass at a time is the default; with
                                        RT_HIP_LANES=2..4 consecutive passes alternate between that many streams.

@@ -969,6 +969,21 @@ void orc_trace_closest(const void* s, uint32_t n, const float* o, const float* d
     }
 }
 
+// hit_triangle (intersects.comp:3-92) of ray i against triangle prim[i] alone: what the shader computes for that pair,
+// whatever the traversal. Misses (and prim = 0xFFFFFFFF) report {inf, 0, 0, 0xFFFFFFFF}.
+void orc_test_triangles(const void* s, uint32_t n, const float* o, const float* d, const uint32_t* prim, void* hits_out) {
+    const Scene& sc = *static_cast<const Scene*>(s);
+    struct H4 { float t, u, v; uint32_t prim; };
+    H4* out = static_cast<H4*>(hits_out);
+    for (uint32_t i = 0; i < n; ++i) {
+        out[i] = {INF, 0.0f, 0.0f, 0xFFFFFFFFu};
+        if (prim[i] >= sc.tris.size()) continue;
+        Ray ray{v3(o + 3 * size_t(i)), v3(d + 3 * size_t(i))};
+        Hit h;
+        if (hit_triangle(sc.tris[prim[i]], ray, false, h)) out[i] = {h.t, h.u, h.v, prim[i]};
+    }
+}
+
 void orc_trace_shadow(const void* s, uint32_t n, const float* o, const float* d, const float* tmax, uint8_t* visible) {
     const Scene& sc = *static_cast<const Scene*>(s);
     for (uint32_t i = 0; i < n; ++i) {

@@ -128,6 +128,14 @@ class OracleScene:
         lib().orc_trace_brute(self.h, C.c_uint32(len(o)), _p(o), _p(d), _p(hits))
         return hits
 
+    def test_triangles(self, o, d, prim):
+        """hit_triangle of ray i against triangle prim[i] alone."""
+        o, d = _f(o, 3), _f(d, 3)
+        prim = np.ascontiguousarray(prim, dtype=np.uint32)
+        hits = np.zeros(len(o), dtype=HIT)
+        lib().orc_test_triangles(self.h, C.c_uint32(len(o)), _p(o), _p(d), _p(prim), _p(hits))
+        return hits
+
     def trace_shadow(self, o, d, tmax):
         o, d, t = _f(o, 3), _f(d, 3), _f(tmax)
         vis = np.zeros(len(o), dtype=np.uint8)

@@ -51,6 +51,7 @@ RT_FIX_ABSORPTION = 1 << 2
 RT_COUNT_TRAVERSAL = 1 << 3
 RT_KERNEL_TIMING = 1 << 4
 RT_SINGLE_STREAM = 1 << 5
+RT_EXACT_ORDER = 1 << 6
 
 
 class RtConfig(C.Structure):

@@ -126,12 +126,14 @@ struct rt_ctx {
     uint32_t slice_first = 0, slice_stride = 1;
     rt_camera cam{};
     bool have_scene = false, have_camera = false;
+    bool fast = true;                         // walk the compressed 4-wide tree (false: RT_EXACT_ORDER)
+    bool camera_within_limit = true;          // the camera sits where the compressed tree's boxes are conservative (SceneDev::origin_limit)
     bool paths_ok = false;                    // path buffers match W x H (false after a resize that ran out of memory)
     int n_cu = 256;
     uint32_t trace_blocks_per_cu = kDefaultTraceBlocksPerCu, shade_blocks_per_cu = kDefaultShadeBlocksPerCu;
 
     // scene
-    DevBuf nodes, wide, isect, shade, mats, lights, light_tris, cdf, texels, tex_table, sky, srgb;
+    DevBuf nodes, wide, cw, isect, shade, mats, lights, light_tris, cdf, texels, tex_table, sky, srgb;
     SceneDev sd{};
     // paths: lane 0 doubles as the working set of the stage-level entry points, which run on the main stream
     Lane lanes[kMaxLanes];
@@ -298,6 +300,15 @@ int clear_accum(rt_ctx* c) {
     return RT_OK;
 }
 
+// Camera rays start within the aperture around the camera location: are they where the compressed tree's boxes are
+// conservative? (Re-evaluated when the camera or the scene changes.)
+void update_camera_limit(rt_ctx* c) {
+    const float reach = std::fabs(c->cam.aperture_radius);
+    bool ok = true;
+    for (int k = 0; k < 3; ++k) ok = ok && (std::fabs(c->cam.location[k]) + reach <= c->sd.origin_limit);
+    c->camera_within_limit = ok;
+}
+
 void refresh_camera(rt_ctx* c) {
     c->cam.resolution[0] = c->W;
     c->cam.resolution[1] = c->H;
@@ -329,8 +340,10 @@ int run_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t frames, uint32_t frame
         const PathDev in = state[b & 1], out = state[(b + 1) & 1];
         {
             StageTimer tm(c, ST_EXTEND, st);
-            if (count) hipLaunchKernelGGL(k_extend<true>, dim3(trace_grid), dim3(kTraceBlock), 0, st, c->sd, in, hit, rin, RT_CURSOR(l.ext_cursor() + b), c->tstats());
-            else hipLaunchKernelGGL(k_extend<false>, dim3(trace_grid), dim3(kTraceBlock), 0, st, c->sd, in, hit, rin, RT_CURSOR(l.ext_cursor() + b), c->tstats());
+            // camera rays may start anywhere; every later ray starts on a surface, inside the scene bounds
+            const bool fast = c->fast && (b != 0 || c->camera_within_limit);
+            auto kern = count ? (fast ? k_extend<true, true> : k_extend<true, false>) : (fast ? k_extend<false, true> : k_extend<false, false>);
+            hipLaunchKernelGGL(kern, dim3(trace_grid), dim3(kTraceBlock), 0, st, c->sd, in, hit, rin, RT_CURSOR(l.ext_cursor() + b), c->tstats());
         }
         {
             StageTimer tm(c, ST_SHADE, st);
@@ -342,7 +355,8 @@ int run_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t frames, uint32_t frame
             StageTimer tm(c, ST_CONNECT, st);
             const bool any = c->sd.has_glass == 0;
             const Regions rsh{l.shard_counts(b) + kQueueShards, c->shard_cap, 0u};
-            auto kern = count ? (any ? k_connect<true, true> : k_connect<true, false>) : (any ? k_connect<false, true> : k_connect<false, false>);
+            auto kern = c->fast ? (count ? (any ? k_connect<true, true, true> : k_connect<true, false, true>) : (any ? k_connect<false, true, true> : k_connect<false, false, true>))
+                                : (count ? (any ? k_connect<true, true, false> : k_connect<true, false, false>) : (any ? k_connect<false, true, false> : k_connect<false, false, false>));
             hipLaunchKernelGGL(kern, dim3(trace_grid), dim3(kTraceBlock), 0, st, c->sd, sq, rad, rsh, RT_CURSOR(l.con_cursor() + b), c->tstats());
         }
     }
@@ -397,6 +411,7 @@ extern "C" int rt_create(const rt_config* cfg, rt_ctx** out) {
     c->device = cfg->device;
     c->W = cfg->width; c->H = cfg->height; c->npix = cfg->width * cfg->height;
     c->max_bounces = mb; c->flags = cfg->flags; c->fpp_cfg = cfg->frames_per_pass;
+    c->fast = (cfg->flags & RT_EXACT_ORDER) == 0;
     auto bail = [&](int code) { std::string m = c->err; rt_destroy(c); fail(nullptr, code, m); return code; };
     if (uint64_t(cfg->width) * cfg->height > 0x7FFFFFFFull) { c->err = "resolution too large"; return bail(RT_ERR_UNSUPPORTED); }
     int rc;
@@ -501,7 +516,7 @@ extern "C" int rt_upload_scene(rt_ctx* c, const void* blob, const uint64_t sizes
 
     // Every table is staged in a fresh buffer and all of them are committed together, so an upload that fails half-way
     // (out of memory, a failed copy) leaves the previous scene in place and renderable.
-    DevBuf nb_nodes, nb_wide, nb_isect, nb_shade, nb_mats, nb_lights, nb_lt, nb_cdf;
+    DevBuf nb_nodes, nb_wide, nb_cw, nb_isect, nb_shade, nb_mats, nb_lights, nb_lt, nb_cdf;
     auto put = [&](DevBuf& b, const void* src, size_t bytes) -> hipError_t {
         hipError_t e = b.ensure(bytes);
         if (e != hipSuccess) return e;
@@ -510,6 +525,7 @@ extern "C" int rt_upload_scene(rt_ctx* c, const void* blob, const uint64_t sizes
     };
     HIPCHK(c, put(nb_nodes, gs.nodes.data(), gs.nodes.size() * sizeof(rtint::NodePair)));
     HIPCHK(c, put(nb_wide, gs.wide.data(), gs.wide.size() * sizeof(rtint::NodeQuad)));
+    HIPCHK(c, put(nb_cw, gs.cw.data(), gs.cw.size() * sizeof(rtint::NodeCw)));
     HIPCHK(c, put(nb_isect, gs.isect.data(), gs.isect.size() * sizeof(rtint::TriIsect)));
     HIPCHK(c, put(nb_shade, gs.shade.data(), gs.shade.size() * sizeof(rtint::TriShade)));
     HIPCHK(c, put(nb_mats, mats, size_t(n_mat) * sizeof(rt_material)));
@@ -519,7 +535,7 @@ extern "C" int rt_upload_scene(rt_ctx* c, const void* blob, const uint64_t sizes
     // nothing queued earlier may still read the tables about to be replaced (every pass on a lane is followed by its
     // accumulation on the main stream, so the main stream is the last to finish)
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->nodes.swap(nb_nodes); c->wide.swap(nb_wide); c->isect.swap(nb_isect); c->shade.swap(nb_shade);
+    c->nodes.swap(nb_nodes); c->wide.swap(nb_wide); c->cw.swap(nb_cw); c->isect.swap(nb_isect); c->shade.swap(nb_shade);
     c->mats.swap(nb_mats); c->lights.swap(nb_lights); c->light_tris.swap(nb_lt); c->cdf.swap(nb_cdf);
 
     SceneDev& sd = c->sd;
@@ -531,6 +547,8 @@ extern "C" int rt_upload_scene(rt_ctx* c, const void* blob, const uint64_t sizes
     sd.wide = c->wide.as<float4>();
     sd.wide_root = gs.wide.empty() ? gs.root_ref : gs.wide_root;     // a leaf (or empty) root has no interior records at all
     sd.n_hot_wide = gs.n_hot_wide;
+    sd.cw = c->cw.as<float4>();
+    sd.origin_limit = 30.0f * gs.scene_size;
     sd.root_ref = gs.root_ref; sd.n_hot = gs.n_hot; sd.n_tri = n_tri; sd.n_light = n_light; sd.n_emissive = n_emissive; sd.n_mat = n_mat;
     // The shader sizes the CDF from its 16-byte padded binding; an empty table is bound as one dummy word
     // (src/vulkan/path_tracer/descriptors.rs:85-93).
@@ -538,6 +556,7 @@ extern "C" int rt_upload_scene(rt_ctx* c, const void* blob, const uint64_t sizes
     if (c->flags & RT_REF_CDF_PAD) seen = uint32_t(want[5] / 4);
     sd.cdf_len_seen = std::max(1u, seen);
     c->have_scene = true;
+    update_camera_limit(c);
     return clear_accum(c);
 }
 
@@ -591,6 +610,7 @@ extern "C" int rt_set_camera(rt_ctx* c, const rt_camera* cam) {
     c->cam = *cam;
     refresh_camera(c);
     c->have_camera = true;
+    update_camera_limit(c);
     return clear_accum(c);
 }
 
@@ -787,6 +807,15 @@ extern "C" int rt_reset_counters(rt_ctx* c) {
 
 // ---- stage-level entry points ---------------------------------------------------------------------------
 
+// True when every origin (n x 3 floats) lies where the compressed tree's boxes are conservative; other rays are traced
+// on the exact path.
+static bool origins_within_limit(const rt_ctx* c, uint32_t n, const float* origins) {
+    const float lim = c->sd.origin_limit;
+    for (size_t i = 0; i < size_t(n) * 3; ++i)
+        if (!(std::fabs(origins[i]) <= lim)) return false;
+    return true;
+}
+
 static int trace_common(rt_ctx* c, uint32_t n, const float* origins, const float* directions, const float* tmax, int shadow,
                         std::vector<float>& host_hits) {
     if (!c->have_scene) return fail(c, RT_ERR_NO_SCENE, "no scene uploaded");
@@ -803,8 +832,9 @@ static int trace_common(rt_ctx* c, uint32_t n, const float* origins, const float
     HIPCHK(c, hipMemsetAsync(c->aux_cursor(), 0, 4, c->stream));
     {
         StageTimer tm(c, shadow ? ST_CONNECT : ST_EXTEND);
-        if (count) hipLaunchKernelGGL(k_trace_rays<true>, dim3(trace_grid_for(c, n, c->trace_blocks_per_cu)), dim3(kTraceBlock), 0, c->stream, c->sd, ro.as<float4>(), rd.as<float4>(), n, shadow, hits.as<float4>(), RT_CURSOR(c->aux_cursor()), c->tstats());
-        else hipLaunchKernelGGL(k_trace_rays<false>, dim3(trace_grid_for(c, n, c->trace_blocks_per_cu)), dim3(kTraceBlock), 0, c->stream, c->sd, ro.as<float4>(), rd.as<float4>(), n, shadow, hits.as<float4>(), RT_CURSOR(c->aux_cursor()), c->tstats());
+        const bool fast = c->fast && origins_within_limit(c, n, origins);
+        auto kern = count ? (fast ? k_trace_rays<true, true> : k_trace_rays<true, false>) : (fast ? k_trace_rays<false, true> : k_trace_rays<false, false>);
+        hipLaunchKernelGGL(kern, dim3(trace_grid_for(c, n, c->trace_blocks_per_cu)), dim3(kTraceBlock), 0, c->stream, c->sd, ro.as<float4>(), rd.as<float4>(), n, shadow, hits.as<float4>(), RT_CURSOR(c->aux_cursor()), c->tstats());
     }
     end_call(c);
     HIPCHK(c, hipGetLastError());
@@ -843,8 +873,10 @@ extern "C" int rt_trace_closest_static(rt_ctx* c, uint32_t n, const float* origi
     HIPCHK(c, hipMemcpyAsync(d_o, origins, size_t(n) * 12, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(d_d, directions, size_t(n) * 12, hipMemcpyHostToDevice, c->stream));
     const uint32_t grid = trace_grid_for(c, n, c->trace_blocks_per_cu);
-    if (c->flags & RT_COUNT_TRAVERSAL) hipLaunchKernelGGL(k_trace_packed<true>, dim3(grid), dim3(kTraceBlock), 0, c->stream, c->sd, d_o, d_d, n, d_h, RT_CURSOR(cursor), c->tstats());
-    else hipLaunchKernelGGL(k_trace_packed<false>, dim3(grid), dim3(kTraceBlock), 0, c->stream, c->sd, d_o, d_d, n, d_h, RT_CURSOR(cursor), c->tstats());
+    const bool count = (c->flags & RT_COUNT_TRAVERSAL) != 0;
+    const bool fast = c->fast && origins_within_limit(c, n, origins);
+    auto kern = count ? (fast ? k_trace_packed<true, true> : k_trace_packed<true, false>) : (fast ? k_trace_packed<false, true> : k_trace_packed<false, false>);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kTraceBlock), 0, c->stream, c->sd, d_o, d_d, n, d_h, RT_CURSOR(cursor), c->tstats());
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(hits, d_h, size_t(n) * sizeof(rt_hit), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -877,9 +909,11 @@ extern "C" int rt_bench_trace(rt_ctx* c, uint32_t n, const float* origins, const
     hipEvent_t a, b;
     HIPCHK(c, hipEventCreate(&a));
     HIPCHK(c, hipEventCreate(&b));
+    const bool fast = c->fast && origins_within_limit(c, n, origins);
+    auto kern = fast ? k_trace_rays<false, true> : k_trace_rays<false, false>;
     auto launch = [&] {
         (void)hipMemsetAsync(c->aux_cursor(), 0, 4, c->stream);
-        hipLaunchKernelGGL(k_trace_rays<false>, dim3(trace_grid_for(c, n, c->trace_blocks_per_cu)), dim3(kTraceBlock), 0, c->stream, c->sd, ro.as<float4>(), rd.as<float4>(), n, shadow, hits.as<float4>(), RT_CURSOR(c->aux_cursor()), c->tstats());
+        hipLaunchKernelGGL(kern, dim3(trace_grid_for(c, n, c->trace_blocks_per_cu)), dim3(kTraceBlock), 0, c->stream, c->sd, ro.as<float4>(), rd.as<float4>(), n, shadow, hits.as<float4>(), RT_CURSOR(c->aux_cursor()), c->tstats());
     };
     launch();  // warm-up
     (void)hipEventRecord(a, c->stream);

@@ -43,6 +43,20 @@ struct alignas(16) NodeQuad {
 };
 static_assert(sizeof(NodeQuad) == 128, "NodeQuad");
 
+// 64-byte record of the compressed 4-wide tree (same topology, record order and references as NodeQuad): child boxes as
+// 8-bit offsets from `p` in steps of `s`, rounded outwards by at least one step and at least GpuScene::box_margin.
+//   box k spans [p + lo[a].byte(k) * s[a], p + hi[a].byte(k) * s[a]] on axis a; an unused entry has lo byte 255 and hi byte 0 (empty for either ray sign) and reference kRefNone.
+struct alignas(16) NodeCw {
+    float p[3];
+    float sx;
+    uint32_t lo[3];
+    uint32_t hix;
+    uint32_t hiy, hiz;
+    float sy, sz;
+    uint32_t ref[4];
+};
+static_assert(sizeof(NodeCw) == 64, "NodeCw");
+
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kLeafMaxCount = 64;
 constexpr uint32_t kLeafMaxFirst = 1u << 25;
@@ -81,6 +95,9 @@ struct GpuScene {
     std::vector<NodeQuad> wide;  // 4-wide tree for occlusion queries (empty when the root is a leaf)
     uint32_t wide_root = kRefNone;
     uint32_t n_hot_wide = 0;     // wide records [0, n_hot_wide) are the largest-area ones, largest first
+    std::vector<NodeCw> cw;      // compressed twin of `wide`, record for record
+    float scene_size = 0.0f;     // largest absolute coordinate of the root bounds
+    float box_margin = 0.0f;     // every compressed box contains its source box grown by this much: 2^-17 * scene_size
     std::vector<TriIsect> isect;
     std::vector<TriShade> shade;
 };

@@ -256,6 +256,64 @@ int convert_scene(const rt_bvh_node* nodes, uint32_t n_nodes, const rt_triangle*
         out.wide_root = slot_of[0];
         out.n_hot_wide = uint32_t(n_hot);
     }
+
+    // ---- compressed twin of the 4-wide tree (see NodeCw) ----
+    {
+        float size = 0.0f;
+        for (int k = 0; k < 3; ++k) {
+            if (std::isfinite(nodes[0].min[k])) size = std::max(size, std::fabs(nodes[0].min[k]));
+            if (std::isfinite(nodes[0].max[k])) size = std::max(size, std::fabs(nodes[0].max[k]));
+        }
+        out.scene_size = size;
+        out.box_margin = std::ldexp(size, -17);
+        const double margin = std::max(double(out.box_margin), 1e-30);
+        out.cw.assign(out.wide.size(), NodeCw{});
+        bool overflow = false;
+        for (size_t s = 0; s < out.wide.size(); ++s) {
+            const NodeQuad& q = out.wide[s];
+            NodeCw& w = out.cw[s];
+            bool usable[4];
+            for (int k = 0; k < 4; ++k) {
+                usable[k] = q.ref[k] != kRefNone;
+                for (int a = 0; a < 3 && usable[k]; ++a)       // NaN or inverted bounds are never entered by the reference's slab test
+                    usable[k] = std::isfinite(q.box[k][a]) && std::isfinite(q.box[k][3 + a]) && q.box[k][a] <= q.box[k][3 + a];
+                w.ref[k] = usable[k] ? q.ref[k] : kRefNone;
+            }
+            uint32_t lo_w[3] = {0, 0, 0}, hi_w[3] = {0, 0, 0};
+            float step[3];
+            for (int a = 0; a < 3; ++a) {
+                double lo_min = 1e300, hi_max = -1e300;
+                for (int k = 0; k < 4; ++k)
+                    if (usable[k]) { lo_min = std::min(lo_min, double(q.box[k][a])); hi_max = std::max(hi_max, double(q.box[k][3 + a])); }
+                if (lo_min > hi_max) { lo_min = hi_max = 0.0; }
+                // origin one margin below the lowest box (rounded down to float), step so that the highest box plus a margin
+                // fits into 253 steps (rounded up to float); at least one margin per step
+                float p = float(lo_min - margin);
+                if (double(p) > lo_min - margin) p = std::nextafter(p, -INFINITY);
+                double ext = hi_max + margin - double(p);
+                float st = float(std::max(ext / 253.0, margin));
+                if (double(st) < std::max(ext / 253.0, margin)) st = std::nextafter(st, INFINITY);
+                w.p[a] = p;
+                step[a] = st;
+                for (int k = 0; k < 4; ++k) {
+                    uint32_t ql = 255u, qh = 0u;                                   // unused: never entered
+                    if (usable[k]) {
+                        long l = long(std::floor((double(q.box[k][a]) - double(p)) / double(st))) - 1;
+                        long h = long(std::ceil((double(q.box[k][3 + a]) - double(p)) / double(st))) + 1;
+                        overflow |= h > 255;
+                        ql = uint32_t(std::min(255L, std::max(0L, l)));
+                        qh = uint32_t(std::min(255L, std::max(0L, h)));
+                    }
+                    lo_w[a] |= ql << (8 * k);
+                    hi_w[a] |= qh << (8 * k);
+                }
+            }
+            w.sx = step[0]; w.sy = step[1]; w.sz = step[2];
+            w.lo[0] = lo_w[0]; w.lo[1] = lo_w[1]; w.lo[2] = lo_w[2];
+            w.hix = hi_w[0]; w.hiy = hi_w[1]; w.hiz = hi_w[2];
+        }
+        if (overflow) { err = "internal: a compressed child box does not fit its 8-bit range"; return RT_ERR_UNSUPPORTED; }
+    }
     return RT_OK;
 }
 

@@ -11,7 +11,7 @@ sample counts, the firefly bound) are size independent."""
 import numpy as np
 import pytest
 
-from util import random_rays, rel_close
+from util import check_hits_up_to_ties, random_rays, rel_close
 
 pytestmark = pytest.mark.gpu
 
@@ -101,13 +101,23 @@ def test_full_size_configs_sampled_parity_and_properties(rt, oracle, scene_cache
     hi = sc.triangles["v"][..., :3].max(axis=(0, 1))
     qo, qd = random_rays(rng, 20000, lo, hi)
     ro, rd = np.concatenate([ro[pick], qo]), np.concatenate([rd[pick], qd])
-    g = r.trace_closest(ro, rd)
     h, _ = o.trace_closest(ro, rd)
+    # exact-order mode: the shader's ids bit for bit
+    x = rt.HipRenderer.create(sc, max_bounces=bounces, flags=rt.api.RT_EXACT_ORDER)
+    g = x.trace_closest(ro, rd)
     assert np.array_equal(g["prim"], h["prim"]) and np.array_equal(g["t"], h["t"])
     assert np.array_equal(g["u"], h["u"]) and np.array_equal(g["v"], h["v"])
     assert (g["prim"] != 0xFFFFFFFF).mean() > 0.3
     tmax = rng.uniform(0.05, 0.5, len(qo)).astype(np.float32) * float(np.linalg.norm(hi - lo))
-    assert np.array_equal(r.trace_shadow(qo, qd, tmax), o.trace_shadow(qo, qd, tmax))
+    want_vis = o.trace_shadow(qo, qd, tmax)
+    assert np.array_equal(x.trace_shadow(qo, qd, tmax), want_vis)
+    x.destroy()
+    # default mode (compressed 4-wide tree): the same up to eps-ties
+    g = r.trace_closest(ro, rd)
+    ties, recovered = check_hits_up_to_ties(g, h, o, ro, rd, name)
+    print(f"{name} full size, {bounces} bounces: {len(ro)} rays, {ties} eps-ties, {recovered} hits the reference's box test loses")
+    assert ties <= 0.02 * len(ro) and recovered <= 3
+    assert (r.trace_shadow(qo, qd, tmax) != want_vis).sum() <= 2
     # whole image: two samples, twice -> bit-identical, finite, counted, inside the firefly bound
     r.render(2)
     a = r.read_sum()

@@ -1,0 +1,144 @@
+"""The default traversal (compressed 4-wide tree, conservative boxes, nearest-first order) against the same CPU oracle as
+the exact-order mode. The triangle test is the shader's in both modes, so a ray's hit is bit-identical whenever the same
+triangle wins; the modes may differ only in WHICH triangle wins among candidates a rounding error apart (an eps-tie: the
+shader's answer depends on its visiting order, the default mode's on its own), or where the shader's box test itself loses
+a hit to rounding. util.check_hits_up_to_ties states and checks exactly that, ray by ray, and the tests print the counts."""
+import numpy as np
+import pytest
+
+from util import chain_scene, check_hits_up_to_ties, random_rays, rel_close, two_leaf_scene
+
+pytestmark = pytest.mark.gpu
+
+SCENES = [("cornell", {"width": 64, "height": 64}), ("atrium", {"scale": 0.05, "width": 96, "height": 54}),
+          ("glass_blob", {"scale": 0.05, "width": 96, "height": 54}), ("car", {"scale": 0.03, "width": 96, "height": 54}),
+          ("interior", {"scale": 0.01, "width": 96, "height": 54})]
+
+
+def scene_rays(sc, o, n, seed):
+    rng = np.random.default_rng(seed)
+    lo = sc.triangles["v"][..., :3].min(axis=(0, 1)) - 0.5
+    hi = sc.triangles["v"][..., :3].max(axis=(0, 1)) + 0.5
+    ro, rd = random_rays(rng, n, lo, hi)
+    co, cd, _ = o.generate_rays(2)
+    return np.concatenate([ro, co]), np.concatenate([rd, cd])
+
+
+@pytest.mark.parametrize("spatial", [False, True])
+@pytest.mark.parametrize("name,kw", SCENES)
+def test_default_traversal_equals_oracle_up_to_ties(rt, oracle, scene_cache, name, kw, spatial):
+    sc = scene_cache(name, spatial=spatial, **kw)
+    r = rt.HipRenderer.create(sc, max_bounces=4)
+    o = oracle.OracleScene(sc)
+    ro, rd = scene_rays(sc, o, 20000, 11)
+    g = r.trace_closest(ro, rd)
+    h, _ = o.trace_closest(ro, rd)
+    ties, recovered = check_hits_up_to_ties(g, h, o, ro, rd, name)
+    n = len(ro)
+    print(f"{name}{' (spatial splits)' if spatial else ''}: {n} rays, {(g['prim'] != h['prim']).sum()} ids differ: {ties} eps-ties, {recovered} hits the reference's box test loses")
+    assert ties + recovered <= 0.02 * n                      # duplicated references of a spatial-split tree tie by construction
+    assert recovered <= 1e-4 * n + 1
+    assert (g["prim"] != 0xFFFFFFFF).mean() > 0.3
+    # occlusion queries: any hit below tmax
+    rng = np.random.default_rng(13)
+    tmax = rng.uniform(0.1, 8.0, size=n).astype(np.float32)
+    gv, ov = r.trace_shadow(ro, rd, tmax), o.trace_shadow(ro, rd, tmax)
+    bad = np.flatnonzero(gv != ov)
+    for i in bad:       # may differ only where a blocker sits within rounding distance of tmax, or the reference's box test lost it
+        b = o.trace_brute(ro[i:i + 1], rd[i:i + 1])
+        assert b["prim"][0] != 0xFFFFFFFF and (abs(b["t"][0] - tmax[i]) <= 1e-5 * tmax[i] or (gv[i] == 0 and b["t"][0] < tmax[i])), (name, i)
+    assert len(bad) <= 1e-4 * n + 1
+    r.destroy()
+
+
+def test_default_traversal_on_degenerate_trees(rt, oracle):
+    """A 60-level chain (the stack outgrows LDS), two fat leaves (leaf phase with 1..64 parked lanes and exact duplicates),
+    a single-triangle scene (the root is a leaf) and an empty scene."""
+    from test_oracle import one_triangle_scene
+    from ray_tracer_amd.scene import Scene, default_material, look_at_camera
+    rng = np.random.default_rng(5)
+    for sc, n in ((chain_scene(60), 4096), (chain_scene(64), 512), (two_leaf_scene(), 20000), (two_leaf_scene(), 33), (one_triangle_scene(), 2000)):
+        r = rt.HipRenderer.create(sc, max_bounces=2)
+        o = oracle.OracleScene(sc)
+        lo = sc.triangles["v"][..., :3].min(axis=(0, 1)) - 1.0
+        hi = sc.triangles["v"][..., :3].max(axis=(0, 1)) + 1.0
+        ro, rd = random_rays(rng, n, lo, hi)
+        ro[: n // 2, 2] = lo[2]                                  # half of them start in front and look along +z
+        rd[: n // 2] = [0.02, 0.01, 1.0]
+        rd = (rd / np.linalg.norm(rd, axis=1, keepdims=True)).astype(np.float32)
+        g, (h, _) = r.trace_closest(ro, rd), o.trace_closest(ro, rd)
+        ties, recovered = check_hits_up_to_ties(g, h, o, ro, rd, sc.name)
+        assert recovered == 0
+        assert (g["prim"] != 0xFFFFFFFF).sum() == (h["prim"] != 0xFFFFFFFF).sum()
+        tmax = rng.uniform(0.5, 40.0, n).astype(np.float32)
+        assert np.array_equal(r.trace_shadow(ro, rd, tmax), o.trace_shadow(ro, rd, tmax))
+        r.destroy()
+    cam = look_at_camera(37, 23, (0, 0, 3), (0, 0, 0))
+    empty = Scene(triangles=np.zeros(0, rt.api.TRIANGLE), materials=default_material(1), camera=cam).finalize()
+    r = rt.HipRenderer.create(empty, max_bounces=3)
+    assert (r.trace_closest(np.zeros((5, 3), np.float32), np.tile(np.float32([[0, 0, 1]]), (5, 1)))["prim"] == 0xFFFFFFFF).all()
+    r.render(2)
+    assert np.allclose(r.read_accum()[..., :3], 1.0)
+    r.destroy()
+
+
+def test_rays_from_far_outside_take_the_exact_box_test(rt, oracle, scene_cache):
+    """The compressed boxes are padded for rays that start within 30 scene sizes of the origin. Rays from farther away (a
+    camera 1000 scene sizes out, or caller-supplied rays) are traced with the reference's box arithmetic instead, so the
+    guarantee holds for them too."""
+    import dataclasses
+    from ray_tracer_amd.scene import look_at_camera
+    sc = scene_cache("atrium", scale=0.05, width=96, height=54)
+    size = float(np.abs(sc.triangles["v"][..., :3]).max())
+    far = dataclasses.replace(sc, camera=look_at_camera(96, 54, (1000.0 * size, 6.0, 0.5), (0.0, 6.0, 0.0), focal_length=1000.0))
+    r = rt.HipRenderer.create(far, max_bounces=4)
+    o = oracle.OracleScene(far)
+    ro, rd, _ = o.generate_rays(0)
+    go, gd, _ = r.generate_rays(0)
+    assert np.array_equal(go, ro) and np.array_equal(gd, rd)
+    g, (h, _) = r.trace_closest(ro, rd), o.trace_closest(ro, rd)
+    assert (h["prim"] != 0xFFFFFFFF).mean() > 0.1
+    assert np.array_equal(g["prim"], h["prim"]) and np.array_equal(g["t"], h["t"])       # exact path: no ties at all
+    a = r.render_radiance(0)
+    b, _ = o.render_radiance(0, 4)
+    assert rel_close(a, b, 1e-3, 1e-4).all(axis=-1).mean() > 0.97
+    r.destroy()
+
+
+@pytest.mark.parametrize("name,kw,bounces", [(SCENES[0][0], SCENES[0][1], 4), (SCENES[1][0], SCENES[1][1], 8), (SCENES[2][0], SCENES[2][1], 8),
+                                              (SCENES[3][0], SCENES[3][1], 8), (SCENES[4][0], SCENES[4][1], 8)])
+def test_default_traversal_radiance_vs_oracle(rt, oracle, scene_cache, name, kw, bounces):
+    sc = scene_cache(name, **kw)
+    r = rt.HipRenderer.create(sc, max_bounces=bounces)
+    e = rt.HipRenderer.create(sc, max_bounces=bounces, flags=rt.api.RT_EXACT_ORDER)
+    o = oracle.OracleScene(sc)
+    worst = 1.0
+    for frame in (0, 3):
+        g = r.render_radiance(frame)
+        h, _ = o.render_radiance(frame, bounces)
+        fin = np.isfinite(h).all(axis=-1)
+        worst = min(worst, rel_close(g, h, 1e-3, 1e-4).all(axis=-1)[fin].mean())
+        x = e.render_radiance(frame)
+        print(f"{name} frame {frame}: default vs exact-order mode: {(np.abs(g - x) <= 1e-6 + 1e-5 * np.abs(x)).all(axis=-1).mean():.4f} of pixels equal")
+    assert worst > 0.985, worst
+    r.destroy(); e.destroy()
+
+
+def test_full_size_default_traversal_vs_oracle_sample(rt, oracle, scene_cache):
+    """Benchmark scene at full size (262,267 triangles + spatial-split duplicates, 1920x1080): a sample of the camera rays
+    and of second-bounce-like random rays, tie-aware."""
+    sc = scene_cache("atrium", spatial=True)
+    r = rt.HipRenderer.create(sc, max_bounces=8)
+    o = oracle.OracleScene(sc)
+    ro, rd, _ = r.generate_rays(0)
+    rng = np.random.default_rng(23)
+    pick = rng.choice(len(ro), 40000, replace=False)
+    lo = sc.triangles["v"][..., :3].min(axis=(0, 1))
+    hi = sc.triangles["v"][..., :3].max(axis=(0, 1))
+    qo, qd = random_rays(rng, 20000, lo, hi)
+    ro, rd = np.concatenate([ro[pick], qo]), np.concatenate([rd[pick], qd])
+    g, (h, _) = r.trace_closest(ro, rd), o.trace_closest(ro, rd)
+    ties, recovered = check_hits_up_to_ties(g, h, o, ro, rd, "atrium-262k")
+    print(f"atrium-262k (spatial splits): {len(ro)} rays, {ties} eps-ties, {recovered} hits the reference's box test loses")
+    assert ties <= 0.02 * len(ro) and recovered <= 3
+    r.destroy()

@@ -199,7 +199,7 @@ def test_gltf_scene_renders_like_the_oracle(tmp_path, rt, oracle, lights):
     sc = loaders.from_gltf(build_render_asset(tmp_path), build_lights=lights, log=None)
     assert (len(sc.emissive_tris) > 0) == lights
     w, h = 96, 54
-    r = rt.HipRenderer.create(sc, max_bounces=6, width=w, height=h)
+    r = rt.HipRenderer.create(sc, max_bounces=6, width=w, height=h, flags=rt.api.RT_EXACT_ORDER)
     o = oracle.OracleScene(sc)
     o.set_resolution(w, h)
     go, gd, gs = r.generate_rays(0)

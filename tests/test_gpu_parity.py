@@ -16,6 +16,14 @@ from util import chain_scene, random_rays, rel_close, two_leaf_scene
 pytestmark = pytest.mark.gpu
 GOLD = Path(__file__).resolve().parent / "golden"
 
+
+def exact_renderer(rt, scene, **kw):
+    """A renderer in RT_EXACT_ORDER mode: the reference's tree, box arithmetic, visiting order and tie rules, which is what
+    the bit-exact comparisons of this file are about. The default (compressed 4-wide) traversal is held to the same
+    oracle up to ties in tests/test_fast_traversal.py."""
+    kw["flags"] = kw.get("flags", 0) | rt.api.RT_EXACT_ORDER
+    return rt.HipRenderer.create(scene, **kw)
+
 SCENES = [("cornell", {"width": 64, "height": 64}), ("atrium", {"scale": 0.05, "width": 96, "height": 54}),
           ("glass_blob", {"scale": 0.05, "width": 96, "height": 54}), ("car", {"scale": 0.03, "width": 96, "height": 54}),
           ("interior", {"scale": 0.01, "width": 96, "height": 54})]
@@ -30,7 +38,7 @@ def pair(rt, oracle, scene_cache):
         key = (name, tuple(sorted(kw.items())), bounces, flags)
         if key not in made:
             sc = scene_cache(name, **kw)
-            made[key] = (rt.HipRenderer.create(sc, max_bounces=bounces, flags=flags), oracle.OracleScene(sc), sc)
+            made[key] = (exact_renderer(rt, sc, max_bounces=bounces, flags=flags), oracle.OracleScene(sc), sc)
         return made[key]
     yield get
     for r, _, _ in made.values():
@@ -57,7 +65,7 @@ def test_raygen_with_aperture(rt, oracle, scene_cache):
     cam["focus_distance"] = 5.0
     import dataclasses
     sc2 = dataclasses.replace(sc, camera=cam)
-    r = rt.HipRenderer.create(sc2, max_bounces=2)
+    r = exact_renderer(rt, sc2, max_bounces=2)
     o = oracle.OracleScene(sc2)
     go, gd, gs = r.generate_rays(3)
     oo, od, os_ = o.generate_rays(3)
@@ -98,7 +106,7 @@ def test_extend_bit_exact_on_spatial_split_bvh(rt, oracle, scene_cache):
     with the oracle walking the same tree."""
     sc = scene_cache("atrium", spatial=True, scale=0.05, width=96, height=54)
     assert sc.bvh_stats["duplicated_refs"] > 0
-    r = rt.HipRenderer.create(sc, max_bounces=4)
+    r = exact_renderer(rt, sc, max_bounces=4)
     o = oracle.OracleScene(sc)
     rng = np.random.default_rng(13)
     lo = sc.triangles["v"][..., :3].min(axis=(0, 1)) - 0.5
@@ -126,7 +134,7 @@ def test_extend_single_triangle_known_answers(rt):
     import json
     from test_oracle import one_triangle_scene
     sc = one_triangle_scene()      # root node is a leaf: exercises the no-interior-node path
-    r = rt.HipRenderer.create(sc, max_bounces=2)
+    r = exact_renderer(rt, sc, max_bounces=2)
     for c in json.loads((GOLD / "triangle_hits.json").read_text()):
         d = np.array(c["d"], np.float64)
         if c.get("normalize"):
@@ -144,7 +152,7 @@ def test_extend_single_triangle_known_answers(rt):
 def test_extend_deep_tree_uses_stack_beyond_lds(rt, oracle):
     """A 60-level chain stacks one far leaf per level: exercises the part of the traversal stack that lives outside LDS."""
     sc = chain_scene(60)
-    r = rt.HipRenderer.create(sc, max_bounces=2, flags=rt.api.RT_COUNT_TRAVERSAL)
+    r = exact_renderer(rt, sc, max_bounces=2, flags=rt.api.RT_COUNT_TRAVERSAL)
     o = oracle.OracleScene(sc)
     rng = np.random.default_rng(5)
     n = 4096
@@ -167,7 +175,7 @@ def test_trees_deeper_than_the_stack_bound_are_rejected(rt, oracle):
     """65 stack entries serve 64 levels (main.comp:6); the deepest legal tree traces correctly, one level more is refused
     at upload instead of overrunning the stack."""
     ok = chain_scene(64)
-    r = rt.HipRenderer.create(ok, max_bounces=2)
+    r = exact_renderer(rt, ok, max_bounces=2)
     ro = np.array([[0.1, 0.0, -2.0], [0.3, 0.2, -2.0]], np.float32)
     rd = np.tile(np.array([[0, 0, 1]], np.float32), (2, 1))
     g = r.trace_closest(ro, rd)
@@ -175,7 +183,7 @@ def test_trees_deeper_than_the_stack_bound_are_rejected(rt, oracle):
     assert np.array_equal(g["prim"], h["prim"]) and np.array_equal(g["t"], h["t"])
     r.destroy()
     with pytest.raises(RuntimeError, match="deeper than 64"):
-        rt.HipRenderer.create(chain_scene(65), max_bounces=2)
+        exact_renderer(rt, chain_scene(65), max_bounces=2)
 
 
 @pytest.mark.parametrize("n_rays", [1, 7, 16, 17, 30, 33, 64, 65, 1000, 20000])
@@ -184,7 +192,7 @@ def test_leaf_phase_lane_regrouping_keeps_triangle_order(rt, oracle, n_rays):
     many lanes are parked, and walks leaves larger than the column count in several rounds: ids, distances and
     barycentrics equal the per-ray loop of the oracle, including exact ties between a triangle and its duplicate."""
     sc = two_leaf_scene()
-    r = rt.HipRenderer.create(sc, max_bounces=2, flags=rt.api.RT_COUNT_TRAVERSAL)
+    r = exact_renderer(rt, sc, max_bounces=2, flags=rt.api.RT_COUNT_TRAVERSAL)
     o = oracle.OracleScene(sc)
     rng = np.random.default_rng(100 + n_rays)
     ro = np.stack([rng.uniform(-2, 2, n_rays), rng.uniform(-1, 1, n_rays), np.full(n_rays, 3.0)], 1).astype(np.float32)
@@ -225,7 +233,7 @@ def test_lds_resident_node_prefix_does_not_change_results(rt, oracle, scene_cach
             monkeypatch.delenv("RT_HIP_HOT_NODES", raising=False)
         else:
             monkeypatch.setenv("RT_HIP_HOT_NODES", hot)
-        r = rt.HipRenderer.create(sc, max_bounces=2)
+        r = exact_renderer(rt, sc, max_bounces=2)
         results.append(r.trace_closest(ro, rd))
         r.destroy()
     for g in results:
@@ -255,7 +263,7 @@ def test_occlusion_tree_collapse_respects_boxes_that_are_not_nested(rt, oracle):
     put(4, (0, 0, 0), (1, 1, 1), 1, 1)
     sc.bvh = nodes
     sc.build_lights()
-    r = rt.HipRenderer.create(sc, max_bounces=2)
+    r = exact_renderer(rt, sc, max_bounces=2)
     o = oracle.OracleScene(sc)
     ro = np.array([[2.5, 0.4, 3.0], [0.5, 0.4, 3.0], [5.5, 0.4, 3.0], [3.5, 0.4, 3.0]], np.float32)
     rd = np.tile(np.array([[0, 0, -1]], np.float32), (4, 1))
@@ -273,7 +281,7 @@ def test_scene_reload_replaces_every_device_table(rt, oracle, scene_cache):
     streams and the light tables; hits and visibility follow the scene that is current, larger or smaller."""
     small = two_leaf_scene()
     big = scene_cache("atrium", scale=0.05, width=96, height=54)
-    r = rt.HipRenderer.create(small, max_bounces=2)
+    r = exact_renderer(rt, small, max_bounces=2)
     rng = np.random.default_rng(77)
     for sc in (small, big, small, big):
         r.upload_scene(sc)
@@ -296,7 +304,7 @@ def test_reload_without_skybox_restores_the_white_sky(rt, scene_cache):
     cam = look_at_camera(16, 12, (0, 0, 3), (0, 0, 0))
     empty = Scene(triangles=np.zeros(0, rt.api.TRIANGLE), materials=default_material(1), camera=cam).finalize()
     dark = dataclasses.replace(empty, skybox=np.full((6, 2, 2, 4), 10, np.uint8))
-    r = rt.HipRenderer.create(dark, max_bounces=2)
+    r = exact_renderer(rt, dark, max_bounces=2)
     assert r.render_radiance(0).max() < 0.01              # every ray misses: the dark cube map
     r.upload_scene(empty)
     assert np.array_equal(r.render_radiance(0), np.ones((12, 16, 3), np.float32))
@@ -310,7 +318,7 @@ def test_reload_scene_keeps_the_viewer_in_place(rt, scene_cache):
     upload_scene installs the scene's own camera."""
     import dataclasses
     sc = scene_cache("cornell", width=64, height=64)
-    r = rt.HipRenderer.create(sc, max_bounces=2)
+    r = exact_renderer(rt, sc, max_bounces=2)
     moved = sc.camera.copy()
     moved["location"][0][:3] = (0.3, 1.1, 5.0)
     r.set_camera(moved)
@@ -330,7 +338,7 @@ def test_extend_empty_scene_and_ragged_sizes(rt):
     from ray_tracer_amd.scene import Scene, default_material, look_at_camera
     cam = look_at_camera(37, 23, (0, 0, 3), (0, 0, 0))
     empty = Scene(triangles=np.zeros(0, rt.api.TRIANGLE), materials=default_material(1), camera=cam).finalize()
-    r = rt.HipRenderer.create(empty, max_bounces=3)
+    r = exact_renderer(rt, empty, max_bounces=3)
     h = r.trace_closest(np.zeros((5, 3), np.float32), np.tile(np.array([[0, 0, 1]], np.float32), (5, 1)))
     assert (h["prim"] == 0xFFFFFFFF).all()
     assert len(r.trace_closest(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))) == 0
@@ -343,7 +351,7 @@ def test_extend_empty_scene_and_ragged_sizes(rt):
 
 def test_traversal_counters_equal_oracle(pair, rt, scene_cache, oracle):
     sc = scene_cache("atrium", scale=0.05, width=96, height=54)
-    r = rt.HipRenderer.create(sc, max_bounces=4, flags=rt.api.RT_COUNT_TRAVERSAL)
+    r = exact_renderer(rt, sc, max_bounces=4, flags=rt.api.RT_COUNT_TRAVERSAL)
     o = oracle.OracleScene(sc)
     ro, rd, _ = o.generate_rays(0)
     r.reset_counters()
@@ -458,7 +466,7 @@ def test_radiance_matches_golden(pair):
 
 def test_ray_counts_match_oracle(rt, oracle, scene_cache):
     sc = scene_cache("cornell", width=64, height=64)
-    r = rt.HipRenderer.create(sc, max_bounces=4)
+    r = exact_renderer(rt, sc, max_bounces=4)
     o = oracle.OracleScene(sc)
     r.reset_counters()
     r.render_radiance(1)
@@ -488,7 +496,7 @@ def test_accumulated_mean_vs_oracle_and_golden(pair):
 
 def test_legacy_8bit_accumulator_vs_oracle(rt, oracle, scene_cache):
     sc = scene_cache("cornell", width=64, height=64)
-    r = rt.HipRenderer.create(sc, max_bounces=4, flags=rt.api.RT_REF_RGBA8_ACCUM)
+    r = exact_renderer(rt, sc, max_bounces=4, flags=rt.api.RT_REF_RGBA8_ACCUM)
     r.render(4)
     got = np.round(r.read_accum() * 255).astype(np.int32)
     want = np.load(GOLD / "cornell64.npz")["accum8_4"].astype(np.int32)
@@ -520,8 +528,8 @@ def test_cdf_padding_quirk_switch(rt, oracle):
     mats = default_material(2)
     mats["emission"][1, :3] = 10.0
     sc = Scene(triangles=mesh.triangles(), materials=mats, camera=cam).finalize()
-    good = rt.HipRenderer.create(sc, max_bounces=3)
-    bad = rt.HipRenderer.create(sc, max_bounces=3, flags=rt.api.RT_REF_CDF_PAD)
+    good = exact_renderer(rt, sc, max_bounces=3)
+    bad = exact_renderer(rt, sc, max_bounces=3, flags=rt.api.RT_REF_CDF_PAD)
     o = oracle.OracleScene(sc)
     g = good.render_radiance(0)
     assert np.isfinite(g).all()
@@ -536,7 +544,7 @@ def test_cdf_padding_quirk_switch(rt, oracle):
 def test_absorption_fix_switch(rt, oracle, scene_cache):
     sc = scene_cache("glass_blob", scale=0.05, width=96, height=54)
     o = oracle.OracleScene(sc)
-    r = rt.HipRenderer.create(sc, max_bounces=6, flags=rt.api.RT_FIX_ABSORPTION)
+    r = exact_renderer(rt, sc, max_bounces=6, flags=rt.api.RT_FIX_ABSORPTION)
     g = r.render_radiance(0)
     h, _ = o.render_radiance(0, 6, flags=oracle.F_FIX_ABSORPTION)
     assert rel_close(g, h, 1e-3, 1e-4).all(axis=-1).mean() > 0.97
@@ -548,7 +556,7 @@ def test_large_material_and_light_tables_use_the_global_memory_path(rt, oracle):
     copies, and a glass material forces closest-hit (not first-hit) shadow rays. Same parity bar as everywhere else."""
     from util import big_tables_scene
     sc = big_tables_scene()
-    r = rt.HipRenderer.create(sc, max_bounces=5)
+    r = exact_renderer(rt, sc, max_bounces=5)
     o = oracle.OracleScene(sc)
     g = r.render_radiance(2)
     h, oc = o.render_radiance(2, 5)
@@ -611,7 +619,7 @@ def test_oversized_leaf_is_rejected_cleanly(rt):
     sc.bvh = nodes
     sc.build_lights()
     with pytest.raises(rt.api.RtError) as e:
-        rt.HipRenderer.create(sc, max_bounces=2)
+        exact_renderer(rt, sc, max_bounces=2)
     assert e.value.code == -4
 
 
@@ -684,7 +692,7 @@ def test_full_size_sample_slices_sum_to_the_whole(rt, full_atrium):
 
 def test_full_size_closest_hit_vs_oracle_sample(rt, oracle, full_atrium):
     """At full scene size the oracle is affordable on a sample of the camera rays: ids and distances bit-exact."""
-    r = rt.HipRenderer.create(full_atrium, max_bounces=8)
+    r = exact_renderer(rt, full_atrium, max_bounces=8)
     o = oracle.OracleScene(full_atrium)
     ro, rd, _ = r.generate_rays(0)
     pick = np.random.default_rng(23).choice(len(ro), 50000, replace=False)
