@@ -178,12 +178,15 @@ def main():
         "scene_build_s": t_scene, "bvh_build_ms": scene.bvh_stats.get("build_ms"), "bvh_build_bench": bvh_bench,
     }
 
-    # ---- roofline of the dominant kernel (extend), rank 0 only: HIP-event time per launch, algorithmic bytes from traversal counters
+    # ---- per-kernel resource fractions, rank 0 only. Times are measured live (HIP events around every launch, on the stream
+    # the kernels run on, in a context that runs one pass of the size the timed region used); rays / vertices per launch come
+    # from the library's counters; bytes and instruction counts PER RAY come from the committed rocprofv3 counter passes of
+    # this same workload at this same launch size (tools/profile_r2.sh -> tools/roofline_counters.py), scaled by the rays
+    # this run's launches actually processed. Counters cannot be read from inside this process.
     if rank == 0 and not args.no_roofline:
-        # one pass of the same size as the timed region's passes (the library splits a call evenly over its two lanes, at most
-        # 32 frames of 1080p per pass), so these launches are the size of the ones the trace of the main run shows
         lanes = int(os.environ.get("RT_HIP_LANES", "1"))
-        k = max(1, min(32, -(-args.steps // max(1, lanes))))
+        fpp = args.frames_per_pass or 32
+        k = max(1, min(fpp, -(-args.steps // max(1, lanes))))
         rc = rt.HipRenderer.create(scene, max_bounces=args.bounces, device=local_rank, flags=api.RT_COUNT_TRAVERSAL,
                                    frames_per_pass=args.frames_per_pass)
         rc.render(k)
@@ -191,49 +194,76 @@ def main():
         rc.destroy()
         rtm = rt.HipRenderer.create(scene, max_bounces=args.bounces, device=local_rank, flags=api.RT_KERNEL_TIMING,
                                     frames_per_pass=args.frames_per_pass)
-        rtm.render(k)                # warm-up with a pass of the same size, so every traced launch is comparable
+        rtm.render(k)                # warm-up with a pass of the same size, so every timed launch is comparable
         rtm.reset_accumulator()
         rtm.render(k)
         tm = rtm.last_timer_perf()
         rtm.destroy()
-        b_ext = algorithmic_bytes_extend(c["extend_rays"], c["extend_node_pops"], c["extend_tri_tests"])
-        wide = not bool((scene.materials["spec_trans"] > 0.5).any())
-        b_con = algorithmic_bytes_connect(c["shadow_rays"], c["shadow_node_pops"], c["shadow_tri_tests"], wide)
-        ext_s = tm["extend_ms"] / 1e3
-        achieved = b_ext / ext_s / 1e9 if ext_s > 0 else 0.0
-        # HBM-side bytes per launch of the same kernel, from the committed rocprofv3 counter passes of this exact workload
-        # (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; tools/profile_gpu.sh). Counters cannot be read from inside this process.
-        traffic = None
         prof = {}
-        tfile = ROOT / "profiles" / "r1_v5_traffic.json"
+        pfile = ROOT / "profiles" / "r2_roofline_counters.json"
         default_cfg = (args.scene == "atrium" and args.scale == 1.0 and (args.width, args.height, args.bounces) == (1920, 1080, 8)
                        and args.frames_per_pass == 0 and args.bvh == "spatial")
-        if default_cfg and tfile.exists():
-            prof = json.loads(tfile.read_text()).get("k_extend", {})
-            traffic = prof.get("hbm_bytes_per_launch")
+        if default_cfg and pfile.exists():
+            prof = json.loads(pfile.read_text())
+        wide = not bool((scene.materials["spec_trans"] > 0.5).any())
+        items = {"k_extend": c["extend_rays"], "k_shade": c["extend_rays"], "k_connect": c["shadow_rays"]}
+        ms = {"k_extend": tm["extend_ms"], "k_shade": tm["shade_ms"], "k_connect": tm["connect_ms"]}
+        launches = {"k_extend": tm["extend_launches"], "k_shade": tm["shade_launches"], "k_connect": tm["connect_launches"]}
+        algo = {"k_extend": algorithmic_bytes_extend(c["extend_rays"], c["extend_node_pops"], c["extend_tri_tests"]),
+                "k_connect": algorithmic_bytes_connect(c["shadow_rays"], c["shadow_node_pops"], c["shadow_tri_tests"], wide),
+                "k_shade": c["extend_rays"] * 380.0}
+        # issue cost of the kernels' instruction mix, from tools/micro/valu_rate.hip on this chip (profiles/r1_micro_valu_rate.txt):
+        # mul/sub/fma/cvt 2.6-2.8 cycles per wave-instruction per SIMD, cmp+cndmask 3.85, min3/max3 4.4-4.6; the traversal
+        # loops are about 60 % / 25 % / 15 % of those, the shade kernel mostly the first kind
+        mix_cycles = {"k_extend": 3.2, "k_connect": 3.2, "k_shade": 2.9}
+        per_kernel = {}
+        for kn in ("k_extend", "k_connect", "k_shade"):
+            sec = ms[kn] / 1e3
+            p = prof.get(kn, {})
+            n_l = max(1, launches[kn])
+            e = {"avg_launch_ms": ms[kn] / n_l, "launches": launches[kn], "items_per_launch": items[kn] / n_l,
+                 "item": "vertex" if kn == "k_shade" else "ray",
+                 "mitems_per_s": items[kn] / sec / 1e6 if sec > 0 else 0.0,
+                 "algorithmic_bytes_per_launch": algo[kn] / n_l,
+                 "achieved_algorithmic_GBs": algo[kn] / sec / 1e9 if sec > 0 else 0.0}
+            if p and sec > 0:
+                traffic = p["fabric_bytes_per_item"] * items[kn]            # bytes beyond L2 for the work this run did
+                valu = p["valu_wave_instr_per_item"] * items[kn]
+                cu_cycles = 256 * 2.4e9 * sec                               # upper bound on the cycles available (2.4 GHz peak clock)
+                e.update({"traffic_bytes_per_launch": traffic / n_l, "fabric_GBs": traffic / sec / 1e9,
+                          "hbm_frac_upper_bound": traffic / sec / 1e9 / HBM_PEAK_GBS,
+                          "valu_wave_instr_per_item": p["valu_wave_instr_per_item"],
+                          "valu_issue_frac": valu * mix_cycles[kn] / 4.0 / cu_cycles,
+                          "valu_wave_instr_per_cu_cycle_profiled": p["valu_wave_instr_per_cu_cycle"],
+                          "lanes_active_per_valu_instr": p["lanes_active_per_valu_instr"],
+                          "ta_busy_frac": p["ta_busy_frac"], "td_busy_frac": p["td_busy_frac"],
+                          "td_stalled_on_cache_frac": p["td_stalled_on_cache_frac"], "l2_hit_rate": p["l2_hit_rate"]})
+            per_kernel[kn] = e
+        ext = per_kernel["k_extend"]
         result["roofline"] = {
-            "kernel": "k_extend", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "traffic_note": "bytes per launch beyond L2 (Infinity Cache hits included), profiles/r1_v5_traffic.json; algorithmic bytes "
-                            "charge every node visit to HBM, so achieved exceeds the HBM peak: about 60 % of the node visits are "
-                            "served from LDS-resident records and most of the rest from L1/L2",
-            "measured_in": "a separate context with per-kernel events (single stream: kernels run alone, as in the rocprofv3 "
-                           "single-stream trace under profiles/); the timed region overlaps two passes, which lengthens individual launches",
-            "l2_hit_rate": prof.get("l2_hit_rate"), "active_lanes_per_valu_instruction": prof.get("active_lanes_per_valu_instruction"),
-            "occupancy": "8 waves/SIMD (64 VGPRs; two 1024-thread workgroups per CU, 80 KiB LDS each: 32 KiB stack heads + 47 KiB resident node records)",
-            "bytes_per_launch": b_ext / max(1, tm["extend_launches"]), "avg_launch_ms": tm["extend_ms"] / max(1, tm["extend_launches"]),
-            "launches": tm["extend_launches"], "samples": k,
-            "bytes_per_ray": b_ext / max(1, c["extend_rays"]),
+            "kernel": "k_extend", "bound": "hbm",
+            # bytes that left L2 (Infinity-Cache hits included) per second: an upper bound on what the kernel asks of HBM
+            "achieved": ext.get("fabric_GBs"), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ext.get("hbm_frac_upper_bound"),
+            "traffic": ext.get("traffic_bytes_per_launch"),
+            "limited_by": "vector-ALU issue (valu_issue_frac) together with the CU's vector-memory return path (td_busy_frac); HBM is far from its limit",
+            "valu_issue_frac": ext.get("valu_issue_frac"), "ta_busy_frac": ext.get("ta_busy_frac"), "td_busy_frac": ext.get("td_busy_frac"),
+            "achieved_algorithmic": ext["achieved_algorithmic_GBs"],
+            "achieved_algorithmic_note": "bytes a one-thread-per-ray loop would request (64 B per interior node visit, 48 B per triangle test, "
+                                         "80 B per ray) per second; most of them are served from LDS-resident records and L2, so this "
+                                         "figure is not bounded by the HBM peak and is reported for continuity only",
+            "bytes_per_launch": ext["algorithmic_bytes_per_launch"], "avg_launch_ms": ext["avg_launch_ms"], "launches": ext["launches"],
+            "samples": k, "counters_from": prof.get("source"), "counters_launch_frames": prof.get("launch_frames"),
+            "tree": "binary, reference order (RT_EXACT_ORDER)" if os.environ.get("RT_BENCH_EXACT") else "compressed 4-wide",
             "node_pops_per_ray": c["extend_node_pops"] / max(1, c["extend_rays"]),
             "tri_tests_per_ray": c["extend_tri_tests"] / max(1, c["extend_rays"]),
-            "extend_mrays_per_s": c["extend_rays"] / ext_s / 1e6 if ext_s > 0 else 0.0,
+            "extend_mrays_per_s": ext["mitems_per_s"],
+            "occupancy": "8 waves/SIMD (64 VGPRs; two 1024-thread workgroups per CU, 80 KiB LDS each)",
         }
-        con_s = tm["connect_ms"] / 1e3
-        result["kernel_ms_per_sample"] = {s: tm[f"{s}_ms"] / k for s in ("raygen", "extend", "shade", "connect", "accumulate")}
+        result["roofline_kernels"] = per_kernel
+        result["kernel_ms_per_sample"] = {s_: tm[f"{s_}_ms"] / k for s_ in ("raygen", "extend", "shade", "connect", "accumulate")}
         result["kernel_ms_per_sample"]["total"] = tm["total_ms"] / k
-        result["connect"] = {"achieved_GBs": b_con / con_s / 1e9 if con_s > 0 else 0.0,
-                             "mrays_per_s": c["shadow_rays"] / con_s / 1e6 if con_s > 0 else 0.0,
-                             "tree": "4-wide (any-hit)" if wide else "binary (closest hit, glass rule)",
+        result["connect"] = {"mrays_per_s": per_kernel["k_connect"]["mitems_per_s"],
+                             "tree": "4-wide (any-hit)" if wide else "compressed 4-wide (closest hit, glass rule)",
                              "node_pops_per_ray": c["shadow_node_pops"] / max(1, c["shadow_rays"]),
                              "tri_tests_per_ray": c["shadow_tri_tests"] / max(1, c["shadow_rays"])}
 

@@ -537,7 +537,11 @@ RT_DEV void leaf_phase(const SceneDev& sc, LaneRay& r, unsigned long long parked
     const uint32_t leaf = wave_pull(owner, r.cur);
     const uint32_t first = leaf & 0x01FFFFFFu, count = ((leaf >> 25) & 63u) + 1u;
     const uint32_t my_first = r.cur & 0x01FFFFFFu;
+#ifdef RT_OCCUPANCY_PROBE
+    if (COUNT && lane == 0) ++n_tri;                     // experiment: leaf phases in the triangle counter
+#else
     if (COUNT && parked) { ++n_leaf; n_tri += ((r.cur >> 25) & 63u) + 1u; }
+#endif
     for (uint32_t base = 0;; base += columns) {
         const bool mine = slot_used && base + col < count;
         if (__builtin_amdgcn_ballot_w64(mine) == 0ull) break;
@@ -649,6 +653,9 @@ RT_DEV void trace_persistent(const SceneDev& sc, const Work& work, uint32_t n, u
             const bool at_node = r.cur < kDone;            // lanes without a ray hold kDone
             if (__builtin_amdgcn_ballot_w64(at_node) == 0ull) break;
             if (uint32_t(__popcll(__builtin_amdgcn_ballot_w64(int32_t(r.cur) < 0))) >= kLeafBatch) break;
+#ifdef RT_OCCUPANCY_PROBE
+            if (COUNT && lane == 0) ++n_leaf;            // experiment: wave-level node steps in the leaf counter
+#endif
             if (at_node) {
                 if (COUNT) ++n_node;
                 if (TREE == kTreeCw) cw_step(sc, r, stack, spill, hot.tab, hot.n);
