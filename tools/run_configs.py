@@ -26,7 +26,7 @@ CONFIGS = [
 def main(out_dir=None):
     for name, kw, bounces, spp in CONFIGS:
         t0 = time.time()
-        sc = scenes.GENERATORS[name](**kw).finalize()
+        sc = scenes.GENERATORS[name](**kw).finalize(spatial=True)      # the policy Scene::build_bvh uses upstream
         t_prep = time.time() - t0
         r = rt.HipRenderer.create(sc, max_bounces=bounces)
         r.render(min(4, spp))
