@@ -86,10 +86,11 @@ def main():
     t_scene = time.time() - t0
 
     # BVH build-time baseline (stand-in for the reference's criterion bench, benches/bvh.rs:11-40: clone the triangles,
-    # build, 10 samples): median wall time of the library's binned-SAH builder on this scene, rank 0 only.
+    # build, 10 samples): median wall time of the library's builders on this scene (binned SAH, binned SAH with
+    # spatial splits, and the twin of the reference's plain `Bvh`), rank 0 only.
     bvh_bench = None
     if rank == 0 and not args.no_cpu_baseline:
-        ts, ts_spatial = [], []
+        ts, ts_spatial, ts_sweep = [], [], []
         n_in = 0
         for i in range(10):
             clone = gen(**kw)
@@ -102,10 +103,17 @@ def main():
                 t1 = time.perf_counter()
                 clone.build_bvh(spatial=True)
                 ts_spatial.append((time.perf_counter() - t1) * 1e3)
+                clone = gen(**kw)
+                t1 = time.perf_counter()
+                clone.build_bvh(sweep=True)
+                ts_sweep.append((time.perf_counter() - t1) * 1e3)
         bvh_bench = {"builder": "binned SAH, object splits (BinSah::default parameters)", "triangles": int(n_in),
                      "median_ms": float(np.median(ts)), "min_ms": float(min(ts)), "samples": 10, "threads": min(64, os.cpu_count() or 1),
                      "mtris_per_s": n_in / float(np.median(ts)) / 1e3,
-                     "spatial_splits_median_ms": float(np.median(ts_spatial)), "spatial_splits_samples": 5}
+                     "spatial_splits_median_ms": float(np.median(ts_spatial)), "spatial_splits_samples": 5,
+                     # the other half of benches/bvh.rs:20-37: the reference's plain `Bvh` (8 candidate planes per axis,
+                     # one thread, bvh.rs:183-331)
+                     "sweep_bvh_median_ms": float(np.median(ts_sweep)), "sweep_bvh_samples": 5, "sweep_bvh_threads": 1}
 
     r = rt.HipRenderer.create(scene, max_bounces=args.bounces, device=local_rank, frames_per_pass=args.frames_per_pass)
     from ray_tracer_amd.distributed import frame_slice

@@ -173,6 +173,12 @@ int rt_bvh_build_spatial(const rt_triangle* tris, uint32_t n_tri, const rt_bvh_p
                          float budget_fraction, rt_triangle* tris_out, uint32_t tri_capacity, uint32_t* n_tris_out,
                          rt_bvh_node* nodes, uint32_t node_capacity, uint32_t* n_nodes, rt_bvh_stats* stats);
 
+/* The reference's first builder, `Bvh` (src/accelerators/bvh_based/bvh.rs:183-331; `impl Accelerator for Bvh`): eight
+ * candidate planes per axis, centre-of-extent assignment, a node stays a leaf when its best split does not beat the cost
+ * its parent was split at. Single-threaded like the original; leaves are not capped (the renderer accepts up to 64
+ * triangles per leaf). Same contract and argument meaning as rt_bvh_build; benches/bvh.rs:20-27 times this builder. */
+int rt_bvh_build_sweep(rt_triangle* tris, uint32_t n_tri, rt_bvh_node* nodes, uint32_t* n_nodes, rt_bvh_stats* stats);
+
 /* Emissive-triangle table and un-normalised power CDF, as Scene::build_lights (src/scene/mod.rs:207-270).
  * `emissive` and `cdf` need room for n_tri entries. Call after rt_bvh_build (tri_index refers to leaf order). */
 int rt_build_lights(const rt_triangle* tris, uint32_t n_tri, const rt_material* mats, uint32_t n_mat,

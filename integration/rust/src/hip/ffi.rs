@@ -238,6 +238,13 @@ extern "C" {
         n_nodes: *mut u32,
         stats: *mut RtBvhStats,
     ) -> i32;
+    pub fn rt_bvh_build_sweep(
+        tris: *mut RtTriangle,
+        n_tri: u32,
+        nodes: *mut RtBvhNode,
+        n_nodes: *mut u32,
+        stats: *mut RtBvhStats,
+    ) -> i32;
     pub fn rt_bvh_build_spatial(
         tris: *const RtTriangle,
         n_tri: u32,

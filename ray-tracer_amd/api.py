@@ -103,6 +103,7 @@ API = {
     "rt_version": (C.c_char_p, []),
     "rt_last_error": (C.c_char_p, [_P]),
     "rt_bvh_build": (_I, [_P, _U32, _P, _P, _P, _P]),
+    "rt_bvh_build_sweep": (_I, [_P, _U32, _P, _P, _P]),
     "rt_bvh_build_spatial": (_I, [_P, _U32, _P, C.c_float, C.c_float, _P, _U32, _P, _P, _U32, _P, _P]),
     "rt_build_lights": (_I, [_P, _U32, _P, _U32, _P, _P, _P, _P]),
     "rt_scene_buffer_sizes": (_I, [_U32, _U32, _U32, _U32, _U32, _P]),

@@ -22,40 +22,12 @@
 
 #include "rt_api.h"
 #include "rt_internal.h"
+#include "bvh_common.h"
 
 namespace {
 
-constexpr int kBins = 16;
-constexpr uint32_t kMaxDepth = 64;
+using namespace rtbvh;
 constexpr uint32_t kSharedWorkMin = 8 * 1024;  // ranges at least this big are split one level at a time and shared
-
-struct V3 {
-    float x, y, z;
-    float operator[](int a) const { return a == 0 ? x : (a == 1 ? y : z); }
-};
-inline V3 vmin(V3 a, V3 b) { return {std::min(a.x, b.x), std::min(a.y, b.y), std::min(a.z, b.z)}; }
-inline V3 vmax(V3 a, V3 b) { return {std::max(a.x, b.x), std::max(a.y, b.y), std::max(a.z, b.z)}; }
-inline V3 vsub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
-inline V3 vadd(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
-inline V3 vmul(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
-
-struct Box {
-    V3 lo{std::numeric_limits<float>::infinity(), std::numeric_limits<float>::infinity(),
-          std::numeric_limits<float>::infinity()};
-    V3 hi{-std::numeric_limits<float>::infinity(), -std::numeric_limits<float>::infinity(),
-          -std::numeric_limits<float>::infinity()};
-    void grow(V3 p) { lo = vmin(lo, p); hi = vmax(hi, p); }
-    void grow(V3 a, V3 b) { lo = vmin(lo, a); hi = vmax(hi, b); }
-    float half_area() const {
-        V3 d = vmax(vsub(hi, lo), V3{0, 0, 0});
-        return d.x * d.y + d.y * d.z + d.z * d.x;
-    }
-};
-
-inline int widest_axis(V3 v) {
-    if (v.x >= v.y && v.x >= v.z) return 0;
-    return v.y >= v.z ? 1 : 2;
-}
 
 struct BinSet {
     Box box[3][kBins];
@@ -94,22 +66,6 @@ struct Builder {
         : cfg(p), pmin(mn), pmax(mx), refs(r), arena(2 * r.size() + 2) {}
 
     V3 centroid(uint32_t i) const { return vmul(vadd(pmin[i], pmax[i]), 0.5f); }
-
-    static V3 bin_scale(const Box& c) {
-        V3 ext = vmax(vsub(c.hi, c.lo), V3{0, 0, 0});
-        const float k = float(kBins) * (1.0f - 1e-6f);
-        return {ext.x > 1e-12f ? k / ext.x : 0.0f, ext.y > 1e-12f ? k / ext.y : 0.0f, ext.z > 1e-12f ? k / ext.z : 0.0f};
-    }
-    static void bin_of(V3 cen, V3 origin, V3 scale, int out[3]) {
-        V3 t = vsub(cen, origin);
-        float f[3] = {t.x * scale.x, t.y * scale.y, t.z * scale.z};
-        for (int a = 0; a < 3; ++a) {
-            float v = f[a];
-            if (!(v > 0.0f)) v = 0.0f;
-            if (v > float(kBins - 1)) v = float(kBins - 1);
-            out[a] = int(v);
-        }
-    }
 
     void bounds_of(uint32_t lo, uint32_t hi, Box& g, Box& c) const {
         g = Box{}; c = Box{};

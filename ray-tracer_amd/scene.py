@@ -73,14 +73,17 @@ class Scene:
     # Scene::build_bvh (src/scene/mod.rs:84-115): reorders the triangles in place. `spatial=True` selects the
     # reference's own policy, BinSah::spatial() (bin_sah.rs:94-100,127-134): triangles may then be duplicated.
     def build_bvh(self, threads: int = 0, min_leaf: int = 2, max_leaf: int = 8, spatial: bool = False,
-                  alpha: float = 1e-5, budget: float = 0.3):
+                  alpha: float = 1e-5, budget: float = 0.3, sweep: bool = False):
         lib = load_library()
         n = len(self.triangles)
         self.triangles = np.ascontiguousarray(self.triangles)
         params = api.RtBvhParams(1.0, 1.0, min_leaf, max_leaf, threads)
         stats = api.RtBvhStats()
         n_nodes = C.c_uint32(0)
-        if spatial:
+        if sweep:      # the reference's first builder, `Bvh` (bvh.rs:183-331)
+            nodes = np.zeros(max(1, 2 * n), dtype=BVH_NODE)
+            check(lib.rt_bvh_build_sweep(ptr(self.triangles), n, ptr(nodes), C.byref(n_nodes), C.byref(stats)))
+        elif spatial:
             cap = n + int(n * max(budget, 0.0)) + 1
             out = np.zeros(cap, dtype=TRIANGLE)
             nodes = np.zeros(2 * cap, dtype=BVH_NODE)

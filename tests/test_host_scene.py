@@ -208,3 +208,57 @@ def test_generators_hit_the_reference_asset_counts():
     assert len(g.triangles) == 134_995 and len(g.materials) == 3
     # generators are seeded: same bytes every time
     assert scenes.atrium(scale=0.05).triangles.tobytes() == scenes.atrium(scale=0.05).triangles.tobytes()
+
+
+def test_sweep_builder_honours_the_traversal_contract(oracle):
+    """`Bvh` twin (bvh.rs:183-331): every triangle in exactly one leaf, child boxes inside their parent's, children adjacent,
+    depth within the stack bound; closest hits through the tree equal brute force; a split is kept only when it beats the
+    cost its parent was split at, so the SAH estimate of the tree is finite and leaves are small on a regular scene."""
+    from ray_tracer_amd import scenes
+    from util import random_rays
+    sc = scenes.atrium(width=64, height=36, scale=0.02)
+    n = len(sc.triangles)
+    before = np.sort(sc.triangles["v"].reshape(n, -1), axis=0)
+    sc.build_bvh(sweep=True).build_lights()
+    assert np.array_equal(np.sort(sc.triangles["v"].reshape(n, -1), axis=0), before)        # a permutation of the input
+    nodes = sc.bvh
+    leaves = nodes[nodes["amt"] != 0]
+    assert leaves["amt"].sum() == n and sc.bvh_stats["leaf_count"] == len(leaves) and sc.bvh_stats["max_depth"] <= 64
+    covered = np.zeros(n, np.int32)
+    for lf in leaves:
+        covered[lf["idx"]: lf["idx"] + lf["amt"]] += 1
+    assert (covered == 1).all()
+    inner = np.flatnonzero(nodes["amt"] == 0)
+    for i in inner:
+        for c in (nodes[i]["idx"], nodes[i]["idx"] + 1):
+            assert (nodes[c]["min"] >= nodes[i]["min"] - 1e-6).all() and (nodes[c]["max"] <= nodes[i]["max"] + 1e-6).all()
+    v = sc.triangles["v"][..., :3]
+    for lf in leaves[:200]:
+        tv = v[lf["idx"]: lf["idx"] + lf["amt"]].reshape(-1, 3)
+        assert (tv.min(axis=0) >= lf["min"] - 1e-6).all() and (tv.max(axis=0) <= lf["max"] + 1e-6).all()
+    assert sc.bvh_stats["avg_leaf_size"] < 8
+    o = oracle.OracleScene(sc)
+    rng = np.random.default_rng(3)
+    ro, rd = random_rays(rng, 1500, v.min(axis=(0, 1)), v.max(axis=(0, 1)))
+    a, _ = o.trace_closest(ro, rd)
+    b = o.trace_brute(ro, rd)
+    # Where two triangles meet along an edge both are hit, 1 ulp apart; the slab test of a flat box may then cull the nearer
+    # one once the other has shortened the ray (main.comp:99-104 pushes on a strict `<`), so a handful of rays keep the
+    # neighbour. The binned builder's trees show the same handful.
+    assert (a["t"] == b["t"]).mean() > 0.99 and (a["prim"] == b["prim"]).mean() > 0.99
+    assert np.array_equal(a["t"] < 1e30, b["t"] < 1e30)
+    hit = b["t"] < 1e30
+    np.testing.assert_allclose(a["t"][hit], b["t"][hit], rtol=1e-6)
+
+
+def test_sweep_builder_degenerate_inputs():
+    from ray_tracer_amd.scene import Scene, default_material, look_at_camera, make_triangles
+    cam = look_at_camera(8, 8, (0, 0, 3), (0, 0, 0))
+    empty = Scene(triangles=np.zeros(0, api.TRIANGLE), materials=default_material(1), camera=cam).build_bvh(sweep=True)
+    assert len(empty.bvh) == 1 and empty.bvh[0]["amt"] == 0 and (empty.bvh[0]["min"] > empty.bvh[0]["max"]).all()
+    one = Scene(triangles=make_triangles([[[0, 0, 0], [1, 0, 0], [0, 1, 0]]], None, None, [0]), materials=default_material(1), camera=cam).build_bvh(sweep=True)
+    assert len(one.bvh) == 1 and one.bvh[0]["amt"] == 1
+    # identical triangles cannot be separated by any plane: one leaf, no infinite recursion
+    same = np.repeat(np.array([[[0, 0, 0], [1, 0, 0], [0, 1, 0]]], np.float32), 5, axis=0)
+    st = Scene(triangles=make_triangles(same, None, None, np.zeros(5, np.uint32)), materials=default_material(1), camera=cam).build_bvh(sweep=True)
+    assert len(st.bvh) == 1 and st.bvh[0]["amt"] == 5
