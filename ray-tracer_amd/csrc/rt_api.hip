@@ -432,9 +432,25 @@ extern "C" int rt_create(const rt_config* cfg, rt_ctx** out) {
         int v = std::atoi(env);
         if (v >= 1 && v <= int(kMaxLanes) && !(c->flags & (RT_SINGLE_STREAM | RT_KERNEL_TIMING | RT_REF_RGBA8_ACCUM))) c->n_lanes = uint32_t(v);
     }
+    // Measurement aid: RT_HIP_CUS=<n> confines the render streams to n compute units (a CU-masked stream) and sizes the
+    // persistent grids for n. The driver deals mask bits round-robin over the XCDs, so n is rounded up to a multiple of 8
+    // and every XCD keeps n/8 CUs (an XCD left without CUs would still be handed workgroups and never run them). L2,
+    // Infinity Cache and HBM stay whole: the figure is an upper bound for a true one-eighth partition.
+    uint32_t cu_mask[8] = {0};
+    bool masked = false;
+    if (const char* env = std::getenv("RT_HIP_CUS")) {
+        int v = std::atoi(env);
+        if (v >= 8 && v < c->n_cu && c->n_cu <= 256) {
+            v = (v + 7) & ~7;
+            for (int b = 0; b < v; ++b) cu_mask[b >> 5] |= 1u << (b & 31);
+            c->n_cu = v;
+            masked = true;
+        }
+    }
     for (uint32_t i = 0; i < c->n_lanes; ++i) {
         Lane& l = c->lanes[i];
-        if (hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&l.pass_done, hipEventDisableTiming) != hipSuccess ||
+        hipError_t se = masked ? hipExtStreamCreateWithCUMask(&l.stream, 8, cu_mask) : hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking);
+        if (se != hipSuccess || hipEventCreateWithFlags(&l.pass_done, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&l.consumed, hipEventDisableTiming) != hipSuccess) { c->err = "lane stream/event creation failed"; return bail(RT_ERR_DEVICE); }
     }
     if (hipEventCreateWithFlags(&c->call_mark, hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return bail(RT_ERR_DEVICE); }
