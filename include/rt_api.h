@@ -92,6 +92,17 @@ typedef struct rt_counters {
     uint64_t shadow_leaf_pops;
 } rt_counters;
 
+/* What rt_tune_resident_set measured and did. Index 0: the binary tree (walked under RT_EXACT_ORDER); 1: the compressed
+ * 4-wide tree (closest hits by default); 2: the uncompressed 4-wide tree (shadow rays that may stop at any hit), which
+ * shares its record order with 1. */
+typedef struct rt_tune_report {
+    uint64_t sampled_visits[3];         /* node visits counted (every 16th ray of one sample per pixel)                  */
+    uint32_t resident_records[3];       /* records of that tree a traversal workgroup keeps in LDS                       */
+    float    resident_share_before[3];  /* fraction of the counted visits whose record was among them: old order ...     */
+    float    resident_share_after[3];   /* ... and new order                                                             */
+    uint32_t records_moved[3];          /* records whose slot changed ([2] repeats [1])                                  */
+} rt_tune_report;
+
 /* 16-byte closest-hit record written by the extend stage. prim = 0xFFFFFFFF on a miss. */
 typedef struct rt_hit {
     float    t, u, v;
@@ -221,6 +232,16 @@ int rt_upload_scene(rt_ctx* ctx, const void* blob, const uint64_t sizes[6],
  * (src/vulkan/core/image.rs:307-318, sampler.rs:10-34). skybox == NULL installs the 1x1 white cube, replacing any cube map uploaded earlier
  * (src/scene/mod.rs:49-65). */
 int rt_upload_textures(rt_ctx* ctx, const rt_texture* textures, uint32_t n_textures, const rt_texture* skybox);
+
+/* Orders the node records by measured use, for the scene and camera now installed. The traversal kernels keep the first
+ * records of each tree in LDS; rt_upload_scene fills that prefix by surface area, which ranks nodes by how often a
+ * random ray meets them. This call traces one sample per pixel with per-record visit counters (every 16th ray counts),
+ * moves the most visited records to the front and uploads the re-ordered trees. Rendered values do not change (the trees
+ * and the order their children are visited in are the same); accumulation is neither used nor restarted; the work
+ * counters are left as they were. Waits for queued work first. A later rt_upload_scene goes back to the area order.
+ * `report` may be NULL. No counterpart upstream: the shader reads every node from its storage buffer
+ * (intersects.comp:65-66). */
+int rt_tune_resident_set(rt_ctx* ctx, rt_tune_report* report);
 
 /* update_uniform_buffer (renderer.rs:465-475) + set_camera_pose (renderer.rs:165-168): installs the camera block and
  * restarts accumulation. `resolution`, `view_port_uv` and `frame` in the block are overwritten by the context. */

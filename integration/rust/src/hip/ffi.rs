@@ -160,6 +160,16 @@ pub struct RtCounters {
 
 #[repr(C)]
 #[derive(Clone, Copy)]
+pub struct RtTuneReport {
+    pub sampled_visits: [u64; 3],
+    pub resident_records: [u32; 3],
+    pub resident_share_before: [f32; 3],
+    pub resident_share_after: [f32; 3],
+    pub records_moved: [u32; 3],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
 pub struct RtHit {
     pub t: f32,
     pub u: f32,
@@ -308,6 +318,7 @@ extern "C" {
         n_emissive: u32,
     ) -> i32;
     pub fn rt_upload_textures(ctx: *mut RtCtx, textures: *const RtTexture, n_textures: u32, skybox: *const RtTexture) -> i32;
+    pub fn rt_tune_resident_set(ctx: *mut RtCtx, report: *mut RtTuneReport) -> i32;
     pub fn rt_set_camera(ctx: *mut RtCtx, cam: *const RtCamera) -> i32;
     pub fn rt_resize(ctx: *mut RtCtx, width: u32, height: u32) -> i32;
     pub fn rt_reset_accumulation(ctx: *mut RtCtx) -> i32;

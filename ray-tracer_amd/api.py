@@ -40,6 +40,9 @@ SHADE_RESULT = np.dtype([("emitted", "<f4", 3), ("seed", "<u4"), ("throughput", 
                          ("medium_throughput", "<f4", 3), ("reserved", "<u4")])
 assert SHADE_VERTEX.itemsize == 64 and SHADE_RESULT.itemsize == 144
 RT_STATIC_MAX_RAYS = 1 << 18
+TUNE_REPORT = np.dtype([("sampled_visits", "<u8", 3), ("resident_records", "<u4", 3), ("resident_share_before", "<f4", 3),
+                        ("resident_share_after", "<f4", 3), ("records_moved", "<u4", 3)])
+assert TUNE_REPORT.itemsize == 72
 assert LIGHT.itemsize == 48 and EMISSIVE_TRI.itemsize == 16 and CAMERA.itemsize == 128 and HIT.itemsize == 16
 
 NO_TEXTURE = 0xFFFFFFFF
@@ -128,6 +131,7 @@ API = {
     "rt_last_timings": (_I, [_P, _P]),
     "rt_get_counters": (_I, [_P, _P]),
     "rt_reset_counters": (_I, [_P]),
+    "rt_tune_resident_set": (_I, [_P, _P]),
     "rt_trace_closest": (_I, [_P, _U32, _P, _P, _P]),
     "rt_trace_closest_static": (_I, [_P, _U32, _P, _P, _P]),
     "rt_trace_shadow": (_I, [_P, _U32, _P, _P, _P, _P]),

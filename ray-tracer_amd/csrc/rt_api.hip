@@ -135,6 +135,10 @@ struct rt_ctx {
     // scene
     DevBuf nodes, wide, cw, isect, shade, mats, lights, light_tris, cdf, texels, tex_table, sky, srgb;
     SceneDev sd{};
+    // host copies of the three node arrays, kept for rt_tune_resident_set
+    std::vector<rtint::NodePair> h_nodes;
+    std::vector<rtint::NodeQuad> h_wide;
+    std::vector<rtint::NodeCw> h_cw;
     // paths: lane 0 doubles as the working set of the stage-level entry points, which run on the main stream
     Lane lanes[kMaxLanes];
     uint32_t n_lanes = 1, next_lane = 0;
@@ -553,6 +557,7 @@ extern "C" int rt_upload_scene(rt_ctx* c, const void* blob, const uint64_t sizes
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->nodes.swap(nb_nodes); c->wide.swap(nb_wide); c->cw.swap(nb_cw); c->isect.swap(nb_isect); c->shade.swap(nb_shade);
     c->mats.swap(nb_mats); c->lights.swap(nb_lights); c->light_tris.swap(nb_lt); c->cdf.swap(nb_cdf);
+    c->h_nodes.swap(gs.nodes); c->h_wide.swap(gs.wide); c->h_cw.swap(gs.cw);
 
     SceneDev& sd = c->sd;
     sd.nodes = c->nodes.as<float4>(); sd.isect = c->isect.as<float4>(); sd.shade = c->shade.as<float4>();
@@ -561,7 +566,7 @@ extern "C" int rt_upload_scene(rt_ctx* c, const void* blob, const uint64_t sizes
     sd.has_glass = 0;
     for (uint32_t i = 0; i < n_mat; ++i) sd.has_glass |= mats[i].spec_trans > 0.5f ? 1u : 0u;
     sd.wide = c->wide.as<float4>();
-    sd.wide_root = gs.wide.empty() ? gs.root_ref : gs.wide_root;     // a leaf (or empty) root has no interior records at all
+    sd.wide_root = c->h_wide.empty() ? gs.root_ref : gs.wide_root;     // a leaf (or empty) root has no interior records at all
     sd.n_hot_wide = gs.n_hot_wide;
     sd.cw = c->cw.as<float4>();
     sd.origin_limit = 30.0f * gs.scene_size;
@@ -574,6 +579,95 @@ extern "C" int rt_upload_scene(rt_ctx* c, const void* blob, const uint64_t sizes
     c->have_scene = true;
     update_camera_limit(c);
     return clear_accum(c);
+}
+
+extern "C" int rt_tune_resident_set(rt_ctx* c, rt_tune_report* rep) {
+    if (!c) return RT_ERR_INVALID;
+    if (rep) *rep = rt_tune_report{};
+    int rc;
+    if ((rc = bind_device(c)) != RT_OK) return rc;
+    if ((rc = ready_to_render(c)) != RT_OK) return rc;
+    const size_t nb = c->h_nodes.size(), nw = c->h_wide.size();
+    if (nb + nw == 0) return RT_OK;                              // the root is a leaf: nothing is kept in LDS
+    HIPCHK(c, hipStreamSynchronize(c->stream));                  // every pass is followed by its accumulation on the main stream
+
+    // one sample per pixel through the counting kernels, with the visit counters switched on; the work counters are put back afterwards
+    DevBuf visits;
+    HIPCHK(c, visits.ensure((nb + nw) * sizeof(uint32_t)));
+    HIPCHK(c, hipMemsetAsync(visits.p, 0, (nb + nw) * sizeof(uint32_t), c->stream));
+    TraceStats saved, with;
+    HIPCHK(c, hipMemcpy(&saved, c->stats.p, sizeof(saved), hipMemcpyDeviceToHost));
+    with = saved;
+    with.visits[0] = visits.as<uint32_t>();
+    with.visits[1] = visits.as<uint32_t>() + nb;
+    HIPCHK(c, hipMemcpy(c->stats.p, &with, sizeof(with), hipMemcpyHostToDevice));
+    const uint32_t flags = c->flags;
+    c->flags = (flags | RT_COUNT_TRAVERSAL) & ~uint32_t(RT_KERNEL_TIMING);
+    rc = run_pass(c, c->lanes[0], c->stream, 1, c->slice_first, 1, nullptr);
+    c->flags = flags;
+    const hipError_t se = hipStreamSynchronize(c->stream);
+    saved.visits[0] = saved.visits[1] = nullptr;
+    const hipError_t re = hipMemcpy(c->stats.p, &saved, sizeof(saved), hipMemcpyHostToDevice);
+    if (rc != RT_OK) return rc;
+    HIPCHK(c, se);
+    HIPCHK(c, re);
+    std::vector<uint32_t> v(nb + nw);
+    HIPCHK(c, hipMemcpy(v.data(), visits.p, v.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+
+    auto share = [](const uint32_t* cnt, size_t n, const std::vector<uint32_t>* new_of_old, uint32_t resident, uint64_t& total) {
+        uint64_t in = 0;
+        total = 0;
+        for (size_t i = 0; i < n; ++i) {
+            total += cnt[i];
+            if ((new_of_old ? (*new_of_old)[i] : uint32_t(i)) < resident) in += cnt[i];
+        }
+        return total ? float(double(in) / double(total)) : 0.0f;
+    };
+    std::vector<uint32_t> perm_b, perm_w;
+    const uint32_t moved_b = rtint::order_by_visits(v.data(), nb, c->sd.n_hot, perm_b);
+    const uint32_t moved_w = rtint::order_by_visits(v.data() + nb, nw, c->sd.n_hot_wide, perm_w);
+    if (rep) {
+        const uint32_t res[3] = {std::min<uint32_t>(c->sd.n_hot, kHotLds), std::min<uint32_t>(c->sd.n_hot_wide, kHotLds), std::min<uint32_t>(c->sd.n_hot_wide, kHotWide)};
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t* cnt = k == 0 ? v.data() : v.data() + nb;
+            const size_t n = k == 0 ? nb : nw;
+            uint64_t total = 0;
+            rep->resident_records[k] = res[k];
+            rep->resident_share_before[k] = share(cnt, n, nullptr, res[k], total);
+            rep->resident_share_after[k] = share(cnt, n, k == 0 ? &perm_b : &perm_w, res[k], total);
+            rep->sampled_visits[k] = total;
+            rep->records_moved[k] = k == 0 ? moved_b : moved_w;
+        }
+    }
+    if (moved_b + moved_w == 0) return RT_OK;
+
+    // re-ordered copies, staged and committed together like an upload
+    std::vector<rtint::NodePair> nodes2 = c->h_nodes;
+    std::vector<rtint::NodeQuad> wide2 = c->h_wide;
+    std::vector<rtint::NodeCw> cw2 = c->h_cw;
+    rtint::permute_records(nodes2, perm_b, 2);
+    rtint::permute_records(wide2, perm_w, 4);
+    rtint::permute_records(cw2, perm_w, 4);
+    DevBuf nb_nodes, nb_wide, nb_cw;
+    auto put = [&](DevBuf& b, const void* src, size_t bytes) -> hipError_t {
+        hipError_t e = b.ensure(bytes);
+        if (e != hipSuccess) return e;
+        if (bytes) e = hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice);
+        return e;
+    };
+    HIPCHK(c, put(nb_nodes, nodes2.data(), nodes2.size() * sizeof(rtint::NodePair)));
+    HIPCHK(c, put(nb_wide, wide2.data(), wide2.size() * sizeof(rtint::NodeQuad)));
+    HIPCHK(c, put(nb_cw, cw2.data(), cw2.size() * sizeof(rtint::NodeCw)));
+    c->nodes.swap(nb_nodes); c->wide.swap(nb_wide); c->cw.swap(nb_cw);
+    c->h_nodes.swap(nodes2); c->h_wide.swap(wide2); c->h_cw.swap(cw2);
+    SceneDev& sd = c->sd;
+    sd.nodes = c->nodes.as<float4>(); sd.wide = c->wide.as<float4>(); sd.cw = c->cw.as<float4>();
+    auto renumber = [](uint32_t ref, const std::vector<uint32_t>& perm) {
+        return (!(ref & rtint::kLeafBit) && ref != rtint::kRefNone && ref < perm.size()) ? perm[ref] : ref;
+    };
+    sd.root_ref = renumber(sd.root_ref, perm_b);
+    if (nw != 0) sd.wide_root = renumber(sd.wide_root, perm_w);
+    return RT_OK;
 }
 
 extern "C" int rt_upload_textures(rt_ctx* c, const rt_texture* textures, uint32_t n, const rt_texture* skybox) {

@@ -44,7 +44,7 @@ struct alignas(16) NodeQuad {
 static_assert(sizeof(NodeQuad) == 128, "NodeQuad");
 
 // 64-byte record of the compressed 4-wide tree (same topology, record order and references as NodeQuad): child boxes as
-// 8-bit offsets from `p` in steps of `s`, rounded outwards by at least one step and at least GpuScene::box_margin.
+// 8-bit offsets from `p` in steps of `s`, grown by GpuScene::box_margin and then rounded outwards to the step grid.
 //   box k spans [p + lo[a].byte(k) * s[a], p + hi[a].byte(k) * s[a]] on axis a; an unused entry has lo byte 255 and hi byte 0 (empty for either ray sign) and reference kRefNone.
 struct alignas(16) NodeCw {
     float p[3];
@@ -106,5 +106,26 @@ struct GpuScene {
 // (with `err` filled) when the input violates the traversal contract or a device-layout limit.
 int convert_scene(const rt_bvh_node* nodes, uint32_t n_nodes, const rt_triangle* tris, uint32_t n_tri,
                   const rt_material* mats, uint32_t n_mat, GpuScene& out, std::string& err);
+
+// Record order by measured use. `visits[i]` = how often record i was visited; the `n_hot` most visited records move to
+// slots 0 .. n_hot-1, most visited first (ties: lower old slot first), and the records they push out of that prefix take
+// the slots the newcomers left; every other record stays where it is. Fills new_of_old (old slot -> new slot) and returns
+// the number of records that moved.
+uint32_t order_by_visits(const uint32_t* visits, size_t n_records, uint32_t n_hot, std::vector<uint32_t>& new_of_old);
+
+// Applies such a permutation to a record array: records move to their new slots and every reference to a record
+// (bit 31 clear, not kRefNone) in the first `refs_per_record` words of Rec::ref is renumbered. Leaf references are
+// untouched.
+template <class Rec>
+void permute_records(std::vector<Rec>& recs, const std::vector<uint32_t>& new_of_old, int refs_per_record) {
+    std::vector<Rec> out(recs.size());
+    for (size_t i = 0; i < recs.size(); ++i) {
+        Rec r = recs[i];
+        for (int k = 0; k < refs_per_record; ++k)
+            if (!(r.ref[k] & kLeafBit) && r.ref[k] != kRefNone && r.ref[k] < recs.size()) r.ref[k] = new_of_old[r.ref[k]];
+        out[new_of_old[i]] = r;
+    }
+    recs.swap(out);
+}
 
 }  // namespace rtint

@@ -111,7 +111,12 @@ struct TraceStats {               // all 64-bit, updated with one atomic per wav
     unsigned long long extend_rays, shadow_rays, camera_rays;
     unsigned long long extend_node_pops, extend_leaf_pops, extend_tri_tests;
     unsigned long long shadow_node_pops, shadow_leaf_pops, shadow_tri_tests;
+    // Per-record visit counters (null outside a tuning pass): [0] the binary tree's records, [1] the 4-wide trees' (the
+    // compressed tree shares the uncompressed one's record order). Only the counting kernel variants look at them, and
+    // only for every 16th work item.
+    uint32_t* visits[2];
 };
+constexpr uint32_t kVisitSampleMask = 15u;
 
 // ---- wavefront primitives (64 lanes) -------------------------------------------------------------------
 RT_DEV uint32_t lane_id() { return __lane_id(); }
@@ -403,8 +408,8 @@ RT_DEV void wide_step(const SceneDev& sc, LaneRay& r, lds_u32* stack, uint32_t* 
 // Same topology and record order as the 4-wide tree above, 64 bytes per record instead of 112: the four child boxes are
 // stored as 8-bit offsets from a per-record origin `p` in units of a per-axis step `s`,
 //   chunk 0 {p.x, p.y, p.z, s.x}   chunk 1 {lo.x, lo.y, lo.z, hi.x}   chunk 2 {hi.y, hi.z, s.y, s.z}   chunk 3 {ref 0..3}
-// where each of the six plane words holds one byte per child. The host rounds every box outwards by at least one step
-// and at least 2^-17 of the scene's largest coordinate, which exceeds the rounding error of the fused evaluation below
+// where each of the six plane words holds one byte per child. The host grows every box by 2^-17 of the scene's largest
+// coordinate before rounding it outwards to the step grid, which exceeds the rounding error of the fused evaluation below
 // for every ray that starts within 30 scene sizes of the origin: a box is entered whenever the reference's slab test
 // (intersects.comp:103-121) enters it. Triangles are tested exactly as in the reference, so the hit found is the reference's
 // hit except where another triangle lies within rounding distance of it (the order of visits decides such ties) or where
@@ -580,7 +585,7 @@ RT_DEV void leaf_phase(const SceneDev& sc, LaneRay& r, unsigned long long parked
 constexpr int kTreeBinary = 0, kTreeWide = 1, kTreeCw = 2;
 template <bool COUNT, bool ANYHIT, int TREE, class Work>
 RT_DEV void trace_persistent(const SceneDev& sc, const Work& work, uint32_t n, uint32_t* cursor, lds_u32* stack, lds_u8* slot_owner,
-                             const HotNodes& hot, uint32_t& n_node, uint32_t& n_leaf, uint32_t& n_tri) {
+                             const HotNodes& hot, uint32_t& n_node, uint32_t& n_leaf, uint32_t& n_tri, uint32_t* visits = nullptr) {
     constexpr uint32_t kRefillAt = RT_REFILL_AT;     // refill once this many lanes sit idle
     // consecutive work items a wave owns at a time: RT_CHUNK when there is plenty of work, down to 64 when the queue is
     // short (late bounces), so every resident wave still gets a share
@@ -657,7 +662,10 @@ RT_DEV void trace_persistent(const SceneDev& sc, const Work& work, uint32_t n, u
             if (COUNT && lane == 0) ++n_leaf;            // experiment: wave-level node steps in the leaf counter
 #endif
             if (at_node) {
-                if (COUNT) ++n_node;
+                if (COUNT) {
+                    ++n_node;
+                    if (visits && (r.item & kVisitSampleMask) == 0u) atomicAdd(visits + r.cur, 1u);
+                }
                 if (TREE == kTreeCw) cw_step(sc, r, stack, spill, hot.tab, hot.n);
                 else if (TREE == kTreeWide) wide_step(sc, r, stack, spill, hot.tab, hot.n);
                 else node_step(sc, r, stack, spill, hot);
@@ -814,7 +822,8 @@ __global__ __launch_bounds__(kTraceBlock, RT_TRACE_WAVES_PER_EU) void k_extend(S
     const uint32_t n = load_region_prefix(rg, s_prefix);
     uint32_t n_node = 0, n_leaf = 0, n_tri = 0;
     ExtendWork work{pd, hit, RegionMap{(const lds_u32*)s_prefix, rg.cap, rg.counts == nullptr}};
-    trace_persistent<COUNT, false, TREE>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, (lds_u8*)s_owner + (threadIdx.x & ~63u), hot, n_node, n_leaf, n_tri);
+    trace_persistent<COUNT, false, TREE>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, (lds_u8*)s_owner + (threadIdx.x & ~63u), hot, n_node, n_leaf, n_tri,
+                                         COUNT ? stats->visits[TREE == kTreeBinary ? 0 : 1] : nullptr);
     flush_counts<COUNT>(n_node, n_leaf, n_tri, &stats->extend_node_pops, &stats->extend_leaf_pops, &stats->extend_tri_tests);
 }
 
@@ -832,7 +841,8 @@ __global__ __launch_bounds__(kTraceBlock, RT_TRACE_WAVES_PER_EU) void k_connect(
     const uint32_t n = load_region_prefix(rg, s_prefix);
     uint32_t n_node = 0, n_leaf = 0, n_tri = 0;
     ConnectWork work{sc, sq, rad, RegionMap{(const lds_u32*)s_prefix, rg.cap, rg.counts == nullptr}};
-    trace_persistent<COUNT, ANYHIT, TREE>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, (lds_u8*)s_owner + (threadIdx.x & ~63u), hot, n_node, n_leaf, n_tri);
+    trace_persistent<COUNT, ANYHIT, TREE>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, (lds_u8*)s_owner + (threadIdx.x & ~63u), hot, n_node, n_leaf, n_tri,
+                                          COUNT ? stats->visits[TREE == kTreeBinary ? 0 : 1] : nullptr);
     flush_counts<COUNT>(n_node, n_leaf, n_tri, &stats->shadow_node_pops, &stats->shadow_leaf_pops, &stats->shadow_tri_tests);
 }
 

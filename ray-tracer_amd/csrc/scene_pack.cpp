@@ -229,6 +229,31 @@ int convert_scene(const rt_bvh_node* nodes, uint32_t n_nodes, const rt_triangle*
             return aa != ab ? aa > ab : a < b;
         });
         std::sort(order.begin() + n_hot, order.end());
+        const char* wl = std::getenv("RT_HIP_WIDE_LAYOUT");
+        if (!(wl && std::strcmp(wl, "bfs") == 0)) {
+            // Records outside the hot prefix: the interior children of a record take consecutive slots (a visit stacks up
+            // to three of them and pops them soon after), and the blocks follow each other in the order a depth-first walk
+            // opens them, so a subtree's records share cache lines and pages.
+            std::vector<uint8_t> placed(order.size(), 0);
+            for (size_t k = 0; k < n_hot; ++k) placed[order[k]] = 1;
+            std::vector<uint32_t> rest;
+            rest.reserve(order.size() - n_hot);
+            if (!placed[0]) { placed[0] = 1; rest.push_back(0); }
+            std::vector<uint32_t> walk{0};
+            while (!walk.empty()) {
+                const uint32_t w = walk.back();
+                walk.pop_back();
+                uint32_t e[4], kids[4];
+                const uint32_t n = entries_of(wide_nodes[w], e);
+                uint32_t nk = 0;
+                for (uint32_t k = 0; k < n; ++k)
+                    if (nodes[e[k]].amt == 0) kids[nk++] = wide_of[e[k]];
+                for (uint32_t k = 0; k < nk; ++k)
+                    if (!placed[kids[k]]) { placed[kids[k]] = 1; rest.push_back(kids[k]); }
+                for (uint32_t k = nk; k-- > 0;) walk.push_back(kids[k]);
+            }
+            std::copy(rest.begin(), rest.end(), order.begin() + n_hot);
+        }
         std::vector<uint32_t> slot_of(order.size());
         for (size_t s = 0; s < order.size(); ++s) slot_of[order[s]] = uint32_t(s);
         if (order.size() >= (1u << 25)) { err = "more than 2^25 wide node records"; return RT_ERR_UNSUPPORTED; }
@@ -298,8 +323,8 @@ int convert_scene(const rt_bvh_node* nodes, uint32_t n_nodes, const rt_triangle*
                 for (int k = 0; k < 4; ++k) {
                     uint32_t ql = 255u, qh = 0u;                                   // unused: never entered
                     if (usable[k]) {
-                        long l = long(std::floor((double(q.box[k][a]) - double(p)) / double(st))) - 1;
-                        long h = long(std::ceil((double(q.box[k][3 + a]) - double(p)) / double(st))) + 1;
+                        long l = long(std::floor((double(q.box[k][a]) - margin - double(p)) / double(st)));
+                        long h = long(std::ceil((double(q.box[k][3 + a]) + margin - double(p)) / double(st)));
                         overflow |= h > 255;
                         ql = uint32_t(std::min(255L, std::max(0L, l)));
                         qh = uint32_t(std::min(255L, std::max(0L, h)));
@@ -315,6 +340,28 @@ int convert_scene(const rt_bvh_node* nodes, uint32_t n_nodes, const rt_triangle*
         if (overflow) { err = "internal: a compressed child box does not fit its 8-bit range"; return RT_ERR_UNSUPPORTED; }
     }
     return RT_OK;
+}
+
+uint32_t order_by_visits(const uint32_t* visits, size_t n_records, uint32_t n_hot, std::vector<uint32_t>& new_of_old) {
+    new_of_old.resize(n_records);
+    for (size_t i = 0; i < n_records; ++i) new_of_old[i] = uint32_t(i);
+    const size_t H = std::min<size_t>(n_hot, n_records);
+    if (H == 0) return 0;
+    std::vector<uint32_t> top(n_records);
+    for (size_t i = 0; i < n_records; ++i) top[i] = uint32_t(i);
+    std::partial_sort(top.begin(), top.begin() + H, top.end(), [&](uint32_t a, uint32_t b) {
+        return visits[a] != visits[b] ? visits[a] > visits[b] : a < b;
+    });
+    std::vector<uint8_t> in_top(n_records, 0);
+    for (size_t k = 0; k < H; ++k) in_top[top[k]] = 1;
+    std::vector<uint32_t> vacated, displaced;            // both ascending
+    for (size_t i = H; i < n_records; ++i) if (in_top[i]) vacated.push_back(uint32_t(i));
+    for (size_t i = 0; i < H; ++i) if (!in_top[i]) displaced.push_back(uint32_t(i));
+    for (size_t k = 0; k < H; ++k) new_of_old[top[k]] = uint32_t(k);
+    for (size_t k = 0; k < displaced.size(); ++k) new_of_old[displaced[k]] = vacated[k];
+    uint32_t moved = 0;
+    for (size_t i = 0; i < n_records; ++i) moved += new_of_old[i] != i;
+    return moved;
 }
 
 }  // namespace rtint

@@ -83,6 +83,13 @@ class HipRenderer:
             scene.camera = cam
         self.upload_scene(scene)
 
+    # No counterpart upstream: orders the node records by how often this scene and camera visit them, so the traversal
+    # kernels keep the busiest ones in LDS. Rendered values do not change. Returns what was measured.
+    def tune_resident_set(self) -> dict:
+        rep = np.zeros(1, api.TUNE_REPORT)
+        self._check(self.lib.rt_tune_resident_set(self._ctx, ptr(rep)))
+        return {k: rep[k][0].tolist() for k in rep.dtype.names}
+
     # set_camera_pose (renderer.rs:165-168): location + camera->world rotation (column-major 4x4), restarts accumulation
     def set_camera_pose(self, location, rotation):
         cam = np.ascontiguousarray(self.scene.camera).copy()

@@ -241,6 +241,49 @@ def test_lds_resident_node_prefix_does_not_change_results(rt, oracle, scene_cach
         assert np.array_equal(g["u"], h["u"]) and np.array_equal(g["v"], h["v"])
 
 
+@pytest.mark.parametrize("exact", [True, False], ids=["exact-order", "default"])
+def test_tuning_the_resident_set_changes_no_result(rt, oracle, scene_cache, exact):
+    """rt_tune_resident_set re-orders the node records by measured visits (the busiest ones first, kept in LDS). The trees and
+    the order their children are visited in stay the same, so closest hits, occlusion answers and accumulated radiance are
+    bit-identical before and after, in both traversal modes; the share of visits served from LDS does not drop; the work
+    counters and the accumulator are left alone; a second call finds nothing left to move in the prefix it measured."""
+    sc = scene_cache("atrium", scale=0.05, width=96, height=54)
+    assert (sc.bvh["amt"] == 0).sum() > 2048
+    rng = np.random.default_rng(29)
+    lo = sc.triangles["v"][..., :3].min(axis=(0, 1)) - 0.5
+    hi = sc.triangles["v"][..., :3].max(axis=(0, 1)) + 0.5
+    ro, rd = random_rays(rng, 30000, lo, hi)
+    tmax = rng.uniform(0.5, 20.0, len(ro)).astype(np.float32)
+    r = (exact_renderer if exact else rt.HipRenderer.create)(*((rt, sc) if exact else (sc,)), max_bounces=4, flags=rt.api.RT_COUNT_TRAVERSAL)
+    hits0 = r.trace_closest(ro, rd)
+    occ0 = r.trace_shadow(ro, rd, tmax)
+    r.render(3)
+    img0 = r.read_accum()
+    cnt0 = r.counters()
+    rep = r.tune_resident_set()
+    assert r.counters() == cnt0 and r.sample_count() == 3 and np.array_equal(r.read_accum(), img0, equal_nan=True)
+    k = 0 if exact else 1
+    assert rep["sampled_visits"][k] > 10_000 and rep["records_moved"][k] > 0
+    for j in range(3):
+        assert rep["resident_share_after"][j] >= rep["resident_share_before"][j] - 1e-6
+    assert rep["resident_share_after"][k] > rep["resident_share_before"][k]
+    print(f"resident-set tuning ({'exact' if exact else 'default'}): share of visits served from LDS "
+          f"{rep['resident_share_before']} -> {rep['resident_share_after']}, moved {rep['records_moved']}")
+    hits1 = r.trace_closest(ro, rd)
+    for f in ("t", "u", "v", "prim"):
+        assert np.array_equal(hits0[f], hits1[f])
+    assert np.array_equal(occ0, r.trace_shadow(ro, rd, tmax))
+    r.reset_accumulator()
+    r.render(3)
+    assert np.array_equal(r.read_accum(), img0, equal_nan=True)
+    if exact:
+        h, _ = oracle.OracleScene(sc).trace_closest(ro, rd)
+        assert np.array_equal(hits1["prim"], h["prim"]) and np.array_equal(hits1["t"], h["t"])
+    rep2 = r.tune_resident_set()
+    assert rep2["resident_share_after"][k] >= rep["resident_share_after"][k] - 0.02
+    r.destroy()
+
+
 def test_occlusion_tree_collapse_respects_boxes_that_are_not_nested(rt, oracle):
     """Occlusion queries walk a 4-wide tree collapsed from the binary one, which is exact only where a child's box lies
     inside its parent's. A hand-made tree whose grandchild box sticks out of its parent's box must not be collapsed there:

@@ -1,0 +1,25 @@
+"""Per-kernel time and traversal work per ray for one scene in both traversal modes.
+usage: mode_breakdown.py scene width height [samples]"""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ray_tracer_amd as rt
+from ray_tracer_amd import api, scenes
+
+name, w, h = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+n = int(sys.argv[4]) if len(sys.argv) > 4 else 4
+sc = scenes.GENERATORS[name](width=w, height=h).finalize(spatial=True)
+print(f"{name}: {len(sc.triangles)} triangles", flush=True)
+for mode, flags in (("default", 0), ("exact_order", api.RT_EXACT_ORDER)):
+    r = rt.HipRenderer.create(sc, max_bounces=8, flags=flags | api.RT_KERNEL_TIMING | api.RT_COUNT_TRAVERSAL)
+    r.render(n); r.frame_complete()
+    r.reset_accumulator(); r.reset_counters()
+    r.render(n); r.frame_complete()
+    tm, c = r.last_timer_perf(), r.counters()
+    r.destroy()
+    row = {"mode": mode, "ms_per_sample": {k: tm[f"{k}_ms"] / n for k in ("extend", "shade", "connect")}, "total_ms_per_sample": tm["total_ms"] / n,
+           "extend_rays_per_sample": c["extend_rays"] / n, "shadow_rays_per_sample": c["shadow_rays"] / n,
+           "extend_nodes_per_ray": c["extend_node_pops"] / max(1, c["extend_rays"]), "extend_tris_per_ray": c["extend_tri_tests"] / max(1, c["extend_rays"]),
+           "extend_leaves_per_ray": c["extend_leaf_pops"] / max(1, c["extend_rays"]),
+           "shadow_nodes_per_ray": c["shadow_node_pops"] / max(1, c["shadow_rays"]), "shadow_tris_per_ray": c["shadow_tri_tests"] / max(1, c["shadow_rays"]),
+           "shadow_leaves_per_ray": c["shadow_leaf_pops"] / max(1, c["shadow_rays"])}
+    print(json.dumps(row), flush=True)
