@@ -70,7 +70,7 @@ struct alignas(16) TriIsect {
 };
 // 64-byte shading record, ordered so that a vertex loads only the 16-byte chunks it needs:
 //   chunk 0 {n0.xyz, matword}   chunk 1 {n1.xyz, n2.x}   chunk 2 {n2.yz, uv0.xy}   chunk 3 {uv1.xy, uv2.xy}
-// flat untextured triangles need chunk 0, smooth ones chunks 0-2, textured ones all four.
+// flat untextured triangles need chunk 0 (n0 holds their plane normal), smooth ones chunks 0-2, textured ones all four.
 // matword = material index | bit 31: spec_trans > 0.5 | bit 30: shade_smooth.
 struct alignas(16) TriShade {
     float n0[3];

@@ -923,10 +923,14 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_WAVES) void k_shade(SceneDev sc, P
             } else {
                 const float t = h4.x, u = h4.y, v = h4.z, w = 1.0f - h4.y - h4.z;
                 // The kernel is bound by the rate at which scattered 16-byte loads return, so a vertex fetches only what
-                // it uses: chunk 0 of the shading record always (normal 0 + material word), the other normals for
-                // smooth-shaded triangles, the texture coordinates when the material binds a texture, and the 48-byte
-                // geometry record only for flat normals, tangent frames and the area of an emitter that was hit.
+                // it uses: chunk 0 of the shading record always (normal 0, or the plane normal of a flat triangle, + material
+                // word), the other normals for smooth-shaded triangles, the texture coordinates when the material binds a
+                // texture, and the 48-byte geometry record only for tangent frames and the area of an emitter that was hit.
+#ifdef RT_EXP_DENSE_SHADE
+                const float4* ap = sc.shade + size_t(pin % sc.n_tri) * 4;     // timing experiment only: wrong triangle, dense address
+#else
                 const float4* ap = sc.shade + size_t(prim) * 4;
+#endif
                 const float4 s0 = ap[0];
                 const uint32_t matword = __float_as_uint(s0.w);
                 Mat m;
@@ -940,7 +944,7 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_WAVES) void k_shade(SceneDev sc, P
                 const bool smooth = (matword & 0x40000000u) != 0u;
                 const bool textured = (m.base_tex & m.mr_tex & m.emission_tex & m.normal_tex) != 0xFFFFFFFFu;
                 const bool emitter_mis = sp.bounce > 0 && sc.n_emissive != 0 && num_lights != 0 && luminance(untextured_emission) > 0.0f;
-                const bool need_geometry = !smooth || m.normal_tex != 0xFFFFFFFFu || emitter_mis;
+                const bool need_geometry = m.normal_tex != 0xFFFFFFFFu || emitter_mis;
                 float4 s1 = {}, s2 = {}, s3 = {}, A = {}, B = {}, C = {};
                 if (smooth || textured) s2 = ap[2];
                 if (smooth) s1 = ap[1];
@@ -957,7 +961,7 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_WAVES) void k_shade(SceneDev sc, P
                 if (smooth)
                     normal = normalize(f3{s0.x, s0.y, s0.z} * w + f3{s1.x, s1.y, s1.z} * u + f3{s1.w, s2.x, s2.y} * v);
                 else
-                    normal = f3{A.w, B.w, C.w};
+                    normal = f3{s0.x, s0.y, s0.z};               // the host stores the plane normal here for flat triangles
                 // texture modulation, main.comp:141-159
                 if (m.base_tex != 0xFFFFFFFFu) { f4 c = sample_2d(sc.tex, m.base_tex, uvx, uvy, l_srgb); m.base = m.base * f3{c.x, c.y, c.z}; }
                 if (m.mr_tex != 0xFFFFFFFFu) { f4 c = sample_2d(sc.tex, m.mr_tex, uvx, uvy, l_srgb); m.metallic *= c.z; m.roughness *= c.y; }

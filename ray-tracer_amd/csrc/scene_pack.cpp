@@ -57,6 +57,9 @@ int convert_scene(const rt_bvh_node* nodes, uint32_t n_nodes, const rt_triangle*
         const rt_material& m = mats[t.material_idx];
         if (t.material_idx >= (1u << 30)) { err = "material index too large"; return RT_ERR_UNSUPPORTED; }
         s.matword = t.material_idx | (m.spec_trans > 0.5f ? 0x80000000u : 0u) | (m.shade_smooth ? 0x40000000u : 0u);
+        // a flat-shaded triangle never uses its vertex normals: chunk 0 carries the plane normal instead, so its vertices
+        // read one 16-byte chunk and leave the geometry record alone
+        if (!m.shade_smooth) { s.n0[0] = q.a[3]; s.n0[1] = q.b[3]; s.n0[2] = q.c[3]; }
     }
 
     if (n_tri == 0 || n_nodes == 0) { out.root_ref = kRefNone; return RT_OK; }
