@@ -47,13 +47,15 @@ enum {
     RT_EXACT_ORDER       = 1u << 6, /* closest-hit search exactly as hit_meshes does it (intersects.comp:124-175): the
                                        binary tree, the shader's box arithmetic, visiting order and tie rules, so triangle
                                        ids equal the shader's bit for bit. Without it (the default) rays walk a compressed
-                                       4-wide tree with conservative boxes, about 1.4x faster: distances and ids still
+                                       4-wide tree with conservative boxes, about 1.25x faster in that kernel: distances and ids still
                                        equal the shader's except where two triangles lie within rounding distance of
                                        each other along the ray (either may be reported), or where the shader's own box
                                        test loses a hit to rounding (the hit is then reported).                       */
-    RT_SINGLE_STREAM     = 1u << 5  /* never run two wavefront passes concurrently, whatever RT_HIP_LANES (environment,
-                                       read at rt_create) asks for. One pass at a time is the default; with
-                                       RT_HIP_LANES=2..4 consecutive passes alternate between that many streams.
+    RT_SINGLE_STREAM     = 1u << 5  /* every kernel of every pass on one stream, one after another. By default the
+                                       shadow rays of a bounce run on a side stream beside the next bounce's closest-hit
+                                       search, and short passes (up to 24 Mi paths, 12 frames of 1080p) alternate between
+                                       two sets of path buffers so that consecutive passes overlap; RT_HIP_LANES=1..4
+                                       (environment, read at rt_create) fixes the number of sets for all passes.
                                        Accumulation order, and therefore every output bit, is the same either way.
                                        Implied by RT_KERNEL_TIMING so that per-kernel times are those of kernels
                                        running alone.                                                            */

@@ -5,8 +5,9 @@
 // device layout, the path-state and queue buffers, the fp32 accumulator and the HIP streams on which the
 // kernels of a render call are queued back to back (no host synchronisation inside rt_render).
 //
-// Stream plan: a wavefront pass runs on a `lane` (a stream plus a private set of path-state buffers). By default there
-// is one lane; with RT_HIP_LANES=n consecutive passes alternate between n lanes and overlap. Accumulation of every pass is
+// Stream plan: a wavefront pass runs on a `lane` (a stream, a side stream for its shadow rays, and a private set of
+// path-state buffers). By default there are two lanes and only short passes use the second; with RT_HIP_LANES=n
+// consecutive passes always alternate between n lanes and overlap. Accumulation of every pass is
 // queued on the context's main stream in pass order (it waits on the pass's lane through an event, and the lane's next
 // pass waits until its radiance buffer has been consumed), so the floating-point summation order does not depend on how
 // the lanes interleave.
@@ -58,6 +59,7 @@ struct DevBuf {
 // RT_HIP_TRACE_BLOCKS / RT_HIP_SHADE_BLOCKS override them for tuning runs (read once per context, at creation).
 constexpr uint32_t kDefaultTraceBlocksPerCu = RT_TRACE_WAVES_PER_EU;
 constexpr uint32_t kDefaultShadeBlocksPerCu = 2;
+constexpr uint64_t kSmallPassSlots = 24ull << 20;   // passes of up to this many paths (12 frames of 1080p) alternate between lanes
 
 constexpr uint32_t kMaxLanes = 4;
 
@@ -72,6 +74,10 @@ struct Lane {
     // (their own queue order), per-slot radiance, counters
     DevBuf st_o[2], st_d[2], st_t[2], hit, rad, sq_o, sq_d, sq_c, counts;
     hipEvent_t pass_done = nullptr, consumed = nullptr;
+    // connect(b) and extend(b+1) both need only shade(b): the shadow rays of a bounce run on `side` beside the next
+    // bounce's closest-hit search, each persistent grid filling the compute units the other leaves as it runs down
+    hipStream_t side = nullptr;
+    hipEvent_t shaded = nullptr, connected = nullptr;
     bool busy = false;   // a pass was queued whose radiance the main stream has (or will have) consumed at `consumed`
 
     PathDev state(int k) const { return PathDev{st_o[k].as<float4>(), st_d[k].as<float4>(), st_t[k].as<float4>()}; }
@@ -128,6 +134,8 @@ struct rt_ctx {
     bool have_scene = false, have_camera = false;
     bool fast = true;                         // walk the compressed 4-wide tree (false: RT_EXACT_ORDER)
     bool camera_within_limit = true;          // the camera sits where the compressed tree's boxes are conservative (SceneDev::origin_limit)
+    bool second_lane_for_short_passes = false; // lanes beyond the first take passes of at most kSmallPassSlots paths only
+    bool overlap_connect = true;              // RT_HIP_OVERLAP_CONNECT=0 keeps every launch of a pass on one stream
     bool paths_ok = false;                    // path buffers match W x H (false after a resize that ran out of memory)
     int n_cu = 256;
     uint32_t trace_blocks_per_cu = kDefaultTraceBlocksPerCu, shade_blocks_per_cu = kDefaultShadeBlocksPerCu;
@@ -338,6 +346,9 @@ int run_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t frames, uint32_t frame
     }
     const uint32_t trace_grid = trace_grid_for(c, n_slots, c->trace_blocks_per_cu);
     const uint32_t shade_grid = grid_for(c, n_slots, c->shade_blocks_per_cu);
+    // Shadow rays on the side stream only for passes on the lane's own stream, and never when launches are timed one by one.
+    const bool overlap = c->overlap_connect && st == l.stream && l.side != nullptr && !(c->flags & (RT_KERNEL_TIMING | RT_SINGLE_STREAM));
+    bool connect_pending = false;
     for (uint32_t b = 0; b < c->max_bounces; ++b) {
         // this bounce's paths: every slot at bounce 0, afterwards whatever the previous shade appended to its regions
         const Regions rin = b == 0 ? Regions{nullptr, c->shard_cap, n_slots} : Regions{l.shard_counts(b - 1), c->shard_cap, 0u};
@@ -349,6 +360,8 @@ int run_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t frames, uint32_t frame
             auto kern = count ? (fast ? k_extend<true, true> : k_extend<true, false>) : (fast ? k_extend<false, true> : k_extend<false, false>);
             hipLaunchKernelGGL(kern, dim3(trace_grid), dim3(kTraceBlock), 0, st, c->sd, in, hit, rin, RT_CURSOR(l.ext_cursor() + b), c->tstats());
         }
+        // shade rewrites the light-sample queue and adds to the radiance slots the previous bounce's shadow rays still use
+        if (connect_pending) { HIPCHK(c, hipStreamWaitEvent(st, l.connected, 0)); connect_pending = false; }
         {
             StageTimer tm(c, ST_SHADE, st);
             ShadeParams sp{b, c->max_bounces, c->flags, rin, hit, out, l.shard_counts(b), sq, l.shard_counts(b) + kQueueShards, c->shard_cap, rad, nullptr};
@@ -356,14 +369,24 @@ int run_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t frames, uint32_t frame
             else hipLaunchKernelGGL((k_shade<false, false>), dim3(shade_grid), dim3(kBlock), 0, st, c->sd, in, sp);
         }
         if (c->sd.n_light + c->sd.n_emissive != 0) {
-            StageTimer tm(c, ST_CONNECT, st);
-            const bool any = c->sd.has_glass == 0;
-            const Regions rsh{l.shard_counts(b) + kQueueShards, c->shard_cap, 0u};
-            auto kern = c->fast ? (count ? (any ? k_connect<true, true, true> : k_connect<true, false, true>) : (any ? k_connect<false, true, true> : k_connect<false, false, true>))
-                                : (count ? (any ? k_connect<true, true, false> : k_connect<true, false, false>) : (any ? k_connect<false, true, false> : k_connect<false, false, false>));
-            hipLaunchKernelGGL(kern, dim3(trace_grid), dim3(kTraceBlock), 0, st, c->sd, sq, rad, rsh, RT_CURSOR(l.con_cursor() + b), c->tstats());
+            hipStream_t cs = st;
+            if (overlap) {
+                HIPCHK(c, hipEventRecord(l.shaded, st));
+                HIPCHK(c, hipStreamWaitEvent(l.side, l.shaded, 0));
+                cs = l.side;
+            }
+            {
+                StageTimer tm(c, ST_CONNECT, cs);
+                const bool any = c->sd.has_glass == 0;
+                const Regions rsh{l.shard_counts(b) + kQueueShards, c->shard_cap, 0u};
+                auto kern = c->fast ? (count ? (any ? k_connect<true, true, true> : k_connect<true, false, true>) : (any ? k_connect<false, true, true> : k_connect<false, false, true>))
+                                    : (count ? (any ? k_connect<true, true, false> : k_connect<true, false, false>) : (any ? k_connect<false, true, false> : k_connect<false, false, false>));
+                hipLaunchKernelGGL(kern, dim3(trace_grid), dim3(kTraceBlock), 0, cs, c->sd, sq, rad, rsh, RT_CURSOR(l.con_cursor() + b), c->tstats());
+            }
+            if (overlap) { HIPCHK(c, hipEventRecord(l.connected, l.side)); connect_pending = true; }
         }
     }
+    if (connect_pending) HIPCHK(c, hipStreamWaitEvent(st, l.connected, 0));
     HIPCHK(c, hipGetLastError());
     return RT_OK;
 }
@@ -426,15 +449,19 @@ extern "C" int rt_create(const rt_config* cfg, rt_ctx** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) c->n_cu = std::max(1, prop.multiProcessorCount);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return bail(RT_ERR_DEVICE); }
-    // One lane by default: with path state stored in queue order the kernels of one pass keep the machine busy on their
-    // own, and a second concurrent pass only evicts the first one's BVH lines from L2 / Infinity Cache (measured: 4583 vs
-    // 4446 Mrays/s). RT_HIP_LANES=2..4 still runs consecutive passes on several streams (bit-identical results).
-    c->n_lanes = 1;
+    // Two lanes, the second one for short passes only: a pass of more than kSmallPassSlots paths keeps the machine busy
+    // on its own, and a second concurrent pass only evicts the first one's tree from L2 / Infinity Cache (4583 vs 4446
+    // Mrays/s at 32-frame passes), but short passes (an interactive host renders one sample per call) spend most of
+    // their time running persistent grids down, which the other lane's pass fills (+17 % at one 1080p frame per pass, +6 % at
+    // four, +3.6 % at twelve, -1 % at sixteen). RT_HIP_LANES=1..4 fixes the number of lanes and alternates every pass (bit-identical results either way).
+    c->n_lanes = (c->flags & (RT_SINGLE_STREAM | RT_KERNEL_TIMING | RT_REF_RGBA8_ACCUM)) ? 1 : 2;
+    c->second_lane_for_short_passes = true;
     if (const char* env = std::getenv("RT_HIP_TRACE_BLOCKS")) c->trace_blocks_per_cu = uint32_t(std::max(1, std::atoi(env)));
     if (const char* env = std::getenv("RT_HIP_SHADE_BLOCKS")) c->shade_blocks_per_cu = uint32_t(std::max(1, std::atoi(env)));
+    if (const char* env = std::getenv("RT_HIP_OVERLAP_CONNECT")) c->overlap_connect = std::atoi(env) != 0;
     if (const char* env = std::getenv("RT_HIP_LANES")) {   // tuning aid: 1..4 concurrent passes
         int v = std::atoi(env);
-        if (v >= 1 && v <= int(kMaxLanes) && !(c->flags & (RT_SINGLE_STREAM | RT_KERNEL_TIMING | RT_REF_RGBA8_ACCUM))) c->n_lanes = uint32_t(v);
+        if (v >= 1 && v <= int(kMaxLanes) && !(c->flags & (RT_SINGLE_STREAM | RT_KERNEL_TIMING | RT_REF_RGBA8_ACCUM))) { c->n_lanes = uint32_t(v); c->second_lane_for_short_passes = false; }
     }
     // Measurement aid: RT_HIP_CUS=<n> confines the render streams to n compute units (a CU-masked stream) and sizes the
     // persistent grids for n. The driver deals mask bits round-robin over the XCDs, so n is rounded up to a multiple of 8
@@ -454,6 +481,9 @@ extern "C" int rt_create(const rt_config* cfg, rt_ctx** out) {
     for (uint32_t i = 0; i < c->n_lanes; ++i) {
         Lane& l = c->lanes[i];
         hipError_t se = masked ? hipExtStreamCreateWithCUMask(&l.stream, 8, cu_mask) : hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking);
+        if (se == hipSuccess) se = masked ? hipExtStreamCreateWithCUMask(&l.side, 8, cu_mask) : hipStreamCreateWithFlags(&l.side, hipStreamNonBlocking);
+        if (se == hipSuccess) se = hipEventCreateWithFlags(&l.shaded, hipEventDisableTiming);
+        if (se == hipSuccess) se = hipEventCreateWithFlags(&l.connected, hipEventDisableTiming);
         if (se != hipSuccess || hipEventCreateWithFlags(&l.pass_done, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&l.consumed, hipEventDisableTiming) != hipSuccess) { c->err = "lane stream/event creation failed"; return bail(RT_ERR_DEVICE); }
     }
@@ -485,6 +515,9 @@ extern "C" void rt_destroy(rt_ctx* c) {
     for (Lane& l : c->lanes) {
         if (l.pass_done) (void)hipEventDestroy(l.pass_done);
         if (l.consumed) (void)hipEventDestroy(l.consumed);
+        if (l.shaded) (void)hipEventDestroy(l.shaded);
+        if (l.connected) (void)hipEventDestroy(l.connected);
+        if (l.side) (void)hipStreamDestroy(l.side);
         if (l.stream) (void)hipStreamDestroy(l.stream);
     }
     if (c->call_mark) (void)hipEventDestroy(c->call_mark);
@@ -776,17 +809,20 @@ extern "C" int rt_render(rt_ctx* c, uint32_t n_samples) {
     // everything queued on the main stream so far (clears, uploads, stage-level calls) precedes this call's passes
     HIPCHK(c, hipEventRecord(c->call_mark, c->stream));
     for (uint32_t i = 0; i < c->n_lanes; ++i) HIPCHK(c, hipStreamWaitEvent(c->lanes[i].stream, c->call_mark, 0));
-    // Split the call into passes of at most fpp frames, as even as possible and at least one per lane, so that short
-    // calls still overlap two passes and long ones run the largest passes the path buffers hold (fewer, longer launches:
-    // less time in the ramp-down of each persistent traversal grid).
-    uint32_t n_pass = std::max<uint32_t>((n_samples + c->fpp - 1) / c->fpp, std::min<uint32_t>(c->n_lanes, n_samples));
+    // Split the call into passes of at most fpp frames, as even as possible: long calls run the largest passes the path
+    // buffers hold (fewer, longer launches: less time in the ramp-down of each persistent traversal grid), short passes
+    // alternate between lanes and overlap. With a fixed lane count (RT_HIP_LANES) every call is split into at least one
+    // pass per lane.
+    const uint32_t min_passes = c->second_lane_for_short_passes ? 1u : std::min<uint32_t>(c->n_lanes, n_samples);
+    uint32_t n_pass = std::max<uint32_t>((n_samples + c->fpp - 1) / c->fpp, min_passes);
     uint32_t left = n_samples;
     while (left) {
         uint32_t frames = (left + n_pass - 1) / n_pass;
         --n_pass;
         uint32_t frame_first = c->slice_first + c->local_frame * c->slice_stride;
-        Lane& l = c->lanes[c->next_lane];
-        c->next_lane = (c->next_lane + 1) % c->n_lanes;
+        const bool alternate = !c->second_lane_for_short_passes || uint64_t(frames) * c->npix <= kSmallPassSlots;
+        Lane& l = c->lanes[alternate ? c->next_lane : 0];
+        if (alternate) c->next_lane = (c->next_lane + 1) % c->n_lanes;
         if (l.busy) HIPCHK(c, hipStreamWaitEvent(l.stream, l.consumed, 0));   // its previous radiance has been accumulated
         if ((rc = run_pass(c, l, l.stream, frames, frame_first, c->slice_stride, nullptr)) != RT_OK) return rc;
         HIPCHK(c, hipEventRecord(l.pass_done, l.stream));
