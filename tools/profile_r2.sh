@@ -8,8 +8,8 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd $R
-ARGS="--steps 20 --warmup 5 --no-cpu-baseline $*"
-PM="--steps 20 --warmup 20 --no-cpu-baseline --no-roofline $*"      # warm-up of the same size: every counted launch is a 20-frame launch
+ARGS="--steps 20 --warmup 5 --no-cpu-baseline --no-eighth $*"
+PM="--steps 20 --warmup 20 --no-cpu-baseline --no-roofline --no-eighth $*"      # warm-up of the same size: every counted launch is a 20-frame launch
 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python3 $R/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err || { echo "trace failed"; tail -5 $OUT/trace.err; exit 1; }
 echo trace done
 timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_RD --output-format csv -d $OUT/pmc_a -o bench -- python3 $R/bench.py $PM > $OUT/bench_pmc_a.json 2> $OUT/pmc_a.err || { echo "pmc_a failed"; tail -5 $OUT/pmc_a.err; exit 1; }
