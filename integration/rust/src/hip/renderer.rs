@@ -158,6 +158,14 @@ impl HipRenderer {
         Ok(t)
     }
 
+    /// Orders the node records by measured use for the scene and camera now installed (no counterpart upstream; output
+    /// bits do not change). Worth calling once after `create` / `reload_scene` on scenes whose trees exceed the caches.
+    pub fn tune_resident_set(&mut self) -> Result<RtTuneReport> {
+        let mut rep: RtTuneReport = unsafe { std::mem::zeroed() };
+        check(unsafe { rt_tune_resident_set(self.ctx, &mut rep) }, self.ctx)?;
+        Ok(rep)
+    }
+
     /// Multi-GPU: this renderer takes global frame indices first, first + stride, ... (one renderer per GPU).
     pub fn set_frame_slice(&mut self, first: u32, stride: u32) -> Result<()> {
         check(unsafe { rt_set_frame_slice(self.ctx, first, stride) }, self.ctx)

@@ -36,7 +36,7 @@ constexpr uint32_t kTraceBlock = RT_TRACE_BLOCK;   // workgroup size of the trav
 #define RT_CHUNK 256
 #endif
 #ifndef RT_TAIL_SHIFT
-#define RT_TAIL_SHIFT 3
+#define RT_TAIL_SHIFT 2
 #endif
 #ifndef RT_TAIL_CHUNK
 #define RT_TAIL_CHUNK 64

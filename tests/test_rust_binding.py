@@ -165,3 +165,18 @@ def test_build_script_compiles_the_same_sources_as_the_python_build():
         assert f'"{src.name}"' in rs, src.name
     for flag in ("--offload-arch=gfx950", "-ffp-contract=off", "-shared", "-fPIC"):
         assert flag in rs and flag in mod.FLAGS
+
+
+def test_headless_binary_uses_only_methods_the_facade_has():
+    """`src/bin/headless.rs` (the --spp/--out command line the reference's `main` lacks, src/main.rs:163-181) calls
+    HipRenderer methods by name; every one of them, with its argument count, exists in renderer.rs."""
+    rend = re.sub(r"//.*", "", (RUST / "renderer.rs").read_text())
+    methods = {m.group(1): [a for a in m.group(2).split(",") if a.strip() and "self" not in a]
+               for m in re.finditer(r"pub fn (\w+)\s*\(([^)]*)\)", rend)}
+    src = re.sub(r"//.*", "", (RUST.parent / "bin" / "headless.rs").read_text())
+    calls = re.findall(r"\brenderer\.(\w+)\s*\(([^()]*)\)", src) + re.findall(r"\bHipRenderer::(\w+)\s*\(([^()]*)\)", src)
+    assert {c[0] for c in calls} >= {"create", "dispatch_samples", "frame_complete", "save_frame", "tune_resident_set"}
+    for name, args in calls:
+        assert name in methods, name
+        n_args = len([a for a in args.split(",") if a.strip()])
+        assert n_args == len(methods[name]), (name, n_args, methods[name])
