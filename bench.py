@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-eighth", action="store_true", help="skip the measured 32-CU (one eighth of the chip) leg")
     ap.add_argument("--eighth-child", action="store_true", help=argparse.SUPPRESS)   # internal: run only the 32-CU leg
+    ap.add_argument("--exact-order", action="store_true", help="RT_EXACT_ORDER: the reference's tree and visiting order (bit-exact ids) instead of the default compressed 4-wide tree")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--frames-per-pass", type=int, default=0)
     ap.add_argument("--bvh", choices=("spatial", "object"), default="spatial",
@@ -84,6 +85,7 @@ def main():
             print(f"[bench +{time.time() - t_start:.1f}s] {msg}", file=sys.stderr, flush=True)
     t_start = time.time()
 
+    base_flags = api.RT_EXACT_ORDER if args.exact_order else 0
     gen = scenes.GENERATORS[args.scene]
     kw = {"width": args.width, "height": args.height}
     if args.scene != "cornell":
@@ -96,7 +98,7 @@ def main():
         # The 32-CU leg, in a process of its own: render streams confined to 32 of the 256 compute units (RT_HIP_CUS in
         # rt_api.hip: a CU-masked stream, 4 CUs on each XCD, persistent grids sized for 32).
         os.environ["RT_HIP_CUS"] = "32"
-        r8 = rt.HipRenderer.create(scene, max_bounces=args.bounces, device=local_rank, frames_per_pass=args.frames_per_pass)
+        r8 = rt.HipRenderer.create(scene, max_bounces=args.bounces, device=local_rank, frames_per_pass=args.frames_per_pass, flags=base_flags)
         note("32-CU child: renderer created")
         r8.render(args.warmup)
         r8.frame_complete()
@@ -152,7 +154,7 @@ def main():
                      "sweep_bvh_median_ms": float(np.median(ts_sweep)), "sweep_bvh_samples": 5, "sweep_bvh_threads": 1}
 
     note("scene and build-time baseline done; creating the renderer")
-    r = rt.HipRenderer.create(scene, max_bounces=args.bounces, device=local_rank, frames_per_pass=args.frames_per_pass)
+    r = rt.HipRenderer.create(scene, max_bounces=args.bounces, device=local_rank, frames_per_pass=args.frames_per_pass, flags=base_flags)
     from ray_tracer_amd.distributed import frame_slice
     r.set_frame_slice(*frame_slice(rank, world))
     npix = args.width * args.height
@@ -233,12 +235,12 @@ def main():
         lanes = int(os.environ.get("RT_HIP_LANES", "1"))
         fpp = args.frames_per_pass or 32
         k = max(1, min(fpp, -(-args.steps // max(1, lanes))))
-        rc = rt.HipRenderer.create(scene, max_bounces=args.bounces, device=local_rank, flags=api.RT_COUNT_TRAVERSAL,
+        rc = rt.HipRenderer.create(scene, max_bounces=args.bounces, device=local_rank, flags=api.RT_COUNT_TRAVERSAL | base_flags,
                                    frames_per_pass=args.frames_per_pass)
         rc.render(k)
         c = rc.counters()
         rc.destroy()
-        rtm = rt.HipRenderer.create(scene, max_bounces=args.bounces, device=local_rank, flags=api.RT_KERNEL_TIMING,
+        rtm = rt.HipRenderer.create(scene, max_bounces=args.bounces, device=local_rank, flags=api.RT_KERNEL_TIMING | base_flags,
                                     frames_per_pass=args.frames_per_pass)
         rtm.render(k)                # warm-up with a pass of the same size, so every timed launch is comparable
         rtm.reset_accumulator()
@@ -299,7 +301,7 @@ def main():
                                          "figure is not bounded by the HBM peak and is reported for continuity only",
             "bytes_per_launch": ext["algorithmic_bytes_per_launch"], "avg_launch_ms": ext["avg_launch_ms"], "launches": ext["launches"],
             "samples": k, "counters_from": prof.get("source"), "counters_launch_frames": prof.get("launch_frames"),
-            "tree": "binary, reference order (RT_EXACT_ORDER)" if os.environ.get("RT_BENCH_EXACT") else "compressed 4-wide",
+            "tree": "binary, reference order (RT_EXACT_ORDER)" if args.exact_order else "compressed 4-wide",
             "node_pops_per_ray": c["extend_node_pops"] / max(1, c["extend_rays"]),
             "tri_tests_per_ray": c["extend_tri_tests"] / max(1, c["extend_rays"]),
             "extend_mrays_per_s": ext["mitems_per_s"],
@@ -323,7 +325,7 @@ def main():
         cmd = [sys.executable, os.path.abspath(__file__), "--eighth-child", "--steps", str(max(2, args.steps // 4)),
                "--warmup", str(max(1, args.warmup // 4)), "--width", str(args.width), "--height", str(args.height),
                "--bounces", str(args.bounces), "--scene", args.scene, "--scale", str(args.scale),
-               "--frames-per-pass", str(args.frames_per_pass), "--bvh", args.bvh]
+               "--frames-per-pass", str(args.frames_per_pass), "--bvh", args.bvh] + (["--exact-order"] if args.exact_order else [])
         try:
             env = {k_: v_ for k_, v_ in os.environ.items()
                    if k_ not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE")}

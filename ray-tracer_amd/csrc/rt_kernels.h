@@ -56,7 +56,10 @@ constexpr uint32_t kTraceBlock = RT_TRACE_BLOCK;   // workgroup size of the trav
 constexpr uint32_t kStackLds = RT_STACK_LDS;  // traversal stack entries kept in LDS per lane (4 x kTraceBlock bytes per entry per workgroup)
 constexpr uint32_t kHotLds = RT_HOT_LDS;      // node records (64 B each) every traversal workgroup keeps in LDS
 constexpr uint32_t kStackMax = 65;        // MAX_BVH_DEPTH + 1, main.comp:6 / intersects.comp:130
-constexpr uint32_t kStackMaxWide = 3 * 64 + 1;   // the 4-wide tree stacks up to three entries per level
+#ifndef RT_STACK_MAX_WIDE
+#define RT_STACK_MAX_WIDE (3 * 64 + 1)
+#endif
+constexpr uint32_t kStackMaxWide = RT_STACK_MAX_WIDE;   // the 4-wide tree stacks up to three entries per level
 constexpr uint32_t kHotWide = (RT_HOT_LDS * 64u / 112u) & ~3u;   // 4-wide records (112 B used) in the same LDS bytes
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kRefNone = 0x7FFFFFFFu;
@@ -466,7 +469,9 @@ RT_DEV void cw_step(const SceneDev& sc, LaneRay& r, lds_u32* stack, uint32_t* sp
     const f3 pi = (f3{c0.x, c0.y, c0.z} - r.o) * r.inv;
     const uint32_t lx = __float_as_uint(c1.x), ly = __float_as_uint(c1.y), lz = __float_as_uint(c1.z);
     const uint32_t hx = __float_as_uint(c1.w), hy = __float_as_uint(c2.x), hz = __float_as_uint(c2.y);
-    const bool bx = r.d.x < 0.0f, by = r.d.y < 0.0f, bz = r.d.z < 0.0f;          // the far plane comes first along a negative direction
+    // the far plane comes first along a negative direction; the sign is taken from the reciprocal, which is what the products
+    // below use (a direction component of -0 has a negative reciprocal)
+    const bool bx = r.inv.x < 0.0f, by = r.inv.y < 0.0f, bz = r.inv.z < 0.0f;
     const uint32_t nx = bx ? hx : lx, fx = bx ? lx : hx, ny = by ? hy : ly, fy = by ? ly : hy, nz = bz ? hz : lz, fz = bz ? lz : hz;
     const uint32_t k0 = cw_child_key<0>(r, si, pi, nx, ny, nz, fx, fy, fz);
     const uint32_t k1 = cw_child_key<1>(r, si, pi, nx, ny, nz, fx, fy, fz);
@@ -645,6 +650,21 @@ RT_DEV void trace_persistent(const SceneDev& sc, const Work& work, uint32_t n, u
                 r.t = tmax; r.u = 0.0f; r.v = 0.0f; r.prim = kNoPrim;
                 r.sp = 0; r.tos = kDone;
                 { const uint32_t root = WIDE ? sc.wide_root : sc.root_ref; r.cur = root == kRefNone ? kDone : root; }
+                if (TREE == kTreeCw) {
+                    // The compressed boxes are evaluated as fma(byte, s * inv, (p - o) * inv): an infinite reciprocal (a
+                    // direction component of exactly zero) would turn that into inf - inf = NaN, the axis would drop out of
+                    // the test and the ray would walk every box that overlaps it on the other two axes (measured: 2103
+                    // visits instead of 26 for one such camera ray, a 3 ms tail on a 6 ms launch). A huge finite reciprocal
+                    // keeps the arithmetic finite and still puts both planes of the axis at -huge / +huge when the origin
+                    // lies between them. A ray with a non-finite component hits nothing (every comparison of the
+                    // reference's slab test fails for it as well).
+                    constexpr float kBigInv = 1e30f;
+                    r.inv.x = copysignf(fminf(fabsf(r.inv.x), kBigInv), r.inv.x);
+                    r.inv.y = copysignf(fminf(fabsf(r.inv.y), kBigInv), r.inv.y);
+                    r.inv.z = copysignf(fminf(fabsf(r.inv.z), kBigInv), r.inv.z);
+                    const float probe = (r.o.x + r.o.y + r.o.z) * 0.0f + (r.d.x + r.d.y + r.d.z) * 0.0f;      // 0 for finite input, NaN otherwise
+                    if (!(probe == 0.0f)) r.cur = kDone;
+                }
                 live = true;
             }
             chunk_pos += n_idle < avail ? n_idle : avail;

@@ -82,6 +82,58 @@ def test_default_traversal_on_degenerate_trees(rt, oracle):
     r.destroy()
 
 
+def test_axis_parallel_and_non_finite_rays(rt, oracle, scene_cache):
+    """Direction components of exactly +0 or -0 (an infinite reciprocal) must neither lose hits nor cost more than ordinary
+    rays: the compressed boxes are evaluated with fused multiply-adds, where an infinite reciprocal would give inf - inf and
+    drop the axis from the test, so such a ray would walk every box overlapping it on the other two axes. Rays with a
+    non-finite component hit nothing and cost nothing."""
+    sc = scene_cache("atrium", scale=0.05, width=96, height=54)
+    r = rt.HipRenderer.create(sc, max_bounces=4, flags=rt.api.RT_COUNT_TRAVERSAL)
+    o = oracle.OracleScene(sc)
+    rng = np.random.default_rng(41)
+    lo = sc.triangles["v"][..., :3].min(axis=(0, 1))
+    hi = sc.triangles["v"][..., :3].max(axis=(0, 1))
+    n = 6000
+    ro = rng.uniform(lo, hi, size=(n, 3)).astype(np.float32)
+    rd = rng.normal(size=(n, 3)).astype(np.float32)
+    k = np.arange(n)
+    rd[k % 3 == 0, 0] = 0.0                                  # one zero component ...
+    rd[k % 3 == 1, 1] = -0.0                                 # ... of either sign ...
+    rd[k % 6 == 2, 2] = 0.0
+    rd[k % 12 == 5, 0] = 0.0                                 # ... or two: rays along an axis
+    rd[k % 12 == 5, 1] = -0.0
+    rd = (rd / np.linalg.norm(rd, axis=1, keepdims=True)).astype(np.float32)
+    assert ((rd == 0).sum(axis=1) >= 1).mean() > 0.7
+    r.reset_counters()
+    g = r.trace_closest(ro, rd)
+    zero_cost = r.counters()["extend_node_pops"] / n
+    h, _ = o.trace_closest(ro, rd)
+    ties, recovered = check_hits_up_to_ties(g, h, o, ro, rd, "axis-parallel rays")
+    assert ties + recovered <= 0.02 * n and (g["prim"] != 0xFFFFFFFF).mean() > 0.5
+    rd2 = rng.normal(size=(n, 3)).astype(np.float32)
+    rd2 = (rd2 / np.linalg.norm(rd2, axis=1, keepdims=True)).astype(np.float32)
+    r.reset_counters()
+    r.trace_closest(ro, rd2)
+    ordinary_cost = r.counters()["extend_node_pops"] / n
+    print(f"node visits per ray: {zero_cost:.1f} with zero direction components, {ordinary_cost:.1f} without")
+    assert zero_cost < 1.5 * ordinary_cost
+    tmax = rng.uniform(0.1, 8.0, size=n).astype(np.float32)
+    assert (r.trace_shadow(ro, rd, tmax) != o.trace_shadow(ro, rd, tmax)).sum() <= 2
+    # non-finite directions: no hit, no work
+    bad_o, bad_d = ro[:64].copy(), rd2[:64].copy()
+    bad_d[0::2, 0] = np.nan
+    bad_d[1::2, 2] = np.inf
+    r.reset_counters()
+    gb = r.trace_closest(bad_o, bad_d)
+    assert (gb["prim"] == 0xFFFFFFFF).all() and r.counters()["extend_node_pops"] == 0
+    # non-finite origins lie outside the range the compressed boxes are padded for: such a batch takes the reference's box
+    # arithmetic, where the broken axis drops out of the slab test; still no hit
+    bad_o[0::2, 1] = np.nan
+    bad_o[1::2, 0] = -np.inf
+    assert (r.trace_closest(bad_o, rd2[:64])["prim"] == 0xFFFFFFFF).all()
+    r.destroy()
+
+
 def test_rays_from_far_outside_take_the_exact_box_test(rt, oracle, scene_cache):
     """The compressed boxes are padded for rays that start within 30 scene sizes of the origin. Rays from farther away (a
     camera 1000 scene sizes out, or caller-supplied rays) are traced with the reference's box arithmetic instead, so the

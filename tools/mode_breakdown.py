@@ -6,10 +6,19 @@ import ray_tracer_amd as rt
 from ray_tracer_amd import api, scenes
 
 name, w, h = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-n = int(sys.argv[4]) if len(sys.argv) > 4 else 4
-sc = scenes.GENERATORS[name](width=w, height=h).finalize(spatial=True)
-print(f"{name}: {len(sc.triangles)} triangles", flush=True)
-for mode, flags in (("default", 0), ("exact_order", api.RT_EXACT_ORDER)):
+n = int(sys.argv[4]) if len(sys.argv) > 4 and not sys.argv[4].startswith('--') else 4
+kw = {}
+for a in sys.argv:
+    if a.startswith("--scale="):
+        kw["scale"] = float(a.split("=")[1])
+sc = scenes.GENERATORS[name](width=w, height=h, **kw).finalize(spatial=True)
+print(f"{name}: {len(sc.triangles)} triangles, {len(sc.bvh)} nodes", flush=True)
+modes = [("default", 0), ("exact_order", api.RT_EXACT_ORDER)]
+if "--reverse" in sys.argv:
+    modes.reverse()
+if "--twice" in sys.argv:
+    modes = modes * 2
+for mode, flags in modes:
     r = rt.HipRenderer.create(sc, max_bounces=8, flags=flags | api.RT_KERNEL_TIMING | api.RT_COUNT_TRAVERSAL)
     r.render(n); r.frame_complete()
     r.reset_accumulator(); r.reset_counters()

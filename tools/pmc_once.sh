@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd $R
-timeout -s KILL 200 rocprofv3 --pmc $CTRS --output-format csv -d $OUT -o bench -- python3 $R/bench.py --steps 8 --warmup 8 --no-cpu-baseline --no-roofline --no-eighth "$@" > $OUT/bench.json 2> $OUT/err.txt || { echo "pass failed"; tail -5 $OUT/err.txt; exit 1; }
+timeout -s KILL 200 rocprofv3 --pmc $CTRS --output-format csv -d $OUT -o bench -- python3 $R/bench.py --steps ${PMC_STEPS:-8} --warmup ${PMC_STEPS:-8} --no-cpu-baseline --no-roofline --no-eighth "$@" > $OUT/bench.json 2> $OUT/err.txt || { echo "pass failed"; tail -5 $OUT/err.txt; exit 1; }
 python3 - <<PY
 import csv, collections, glob
 f = glob.glob("$OUT/**/*counter_collection.csv", recursive=True)
