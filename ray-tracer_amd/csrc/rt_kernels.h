@@ -946,11 +946,7 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_WAVES) void k_shade(SceneDev sc, P
                 // it uses: chunk 0 of the shading record always (normal 0, or the plane normal of a flat triangle, + material
                 // word), the other normals for smooth-shaded triangles, the texture coordinates when the material binds a
                 // texture, and the 48-byte geometry record only for tangent frames and the area of an emitter that was hit.
-#ifdef RT_EXP_DENSE_SHADE
-                const float4* ap = sc.shade + size_t(pin % sc.n_tri) * 4;     // timing experiment only: wrong triangle, dense address
-#else
                 const float4* ap = sc.shade + size_t(prim) * 4;
-#endif
                 const float4 s0 = ap[0];
                 const uint32_t matword = __float_as_uint(s0.w);
                 Mat m;
