@@ -59,6 +59,8 @@ struct DevBuf {
 // RT_HIP_TRACE_BLOCKS / RT_HIP_SHADE_BLOCKS override them for tuning runs (read once per context, at creation).
 constexpr uint32_t kDefaultTraceBlocksPerCu = RT_TRACE_WAVES_PER_EU;
 constexpr uint32_t kDefaultShadeBlocksPerCu = 2;
+constexpr float kCheapSlotNs = 1.0f;   // long passes cheaper than this per path (open scenes, tiny scenes) alternate between lanes too:
+                                       // measured 0.47-0.78 ns per path on the car, glass and Cornell scenes, 1.2-2.0 on the atrium and the interior
 constexpr uint64_t kSmallPassSlots = 24ull << 20;   // passes of up to this many paths (12 frames of 1080p) alternate between lanes
 
 constexpr uint32_t kMaxLanes = 4;
@@ -78,6 +80,10 @@ struct Lane {
     // bounce's closest-hit search, each persistent grid filling the compute units the other leaves as it runs down
     hipStream_t side = nullptr;
     hipEvent_t shaded = nullptr, connected = nullptr;
+    // device time of the last pass this lane ran with the machine to itself (harvested by the next rt_render call)
+    hipEvent_t t_begin = nullptr, t_end = nullptr;
+    bool timed = false;
+    uint64_t timed_slots = 0;
     bool busy = false;   // a pass was queued whose radiance the main stream has (or will have) consumed at `consumed`
 
     PathDev state(int k) const { return PathDev{st_o[k].as<float4>(), st_d[k].as<float4>(), st_t[k].as<float4>()}; }
@@ -134,6 +140,7 @@ struct rt_ctx {
     bool have_scene = false, have_camera = false;
     bool fast = true;                         // walk the compressed 4-wide tree (false: RT_EXACT_ORDER)
     bool camera_within_limit = true;          // the camera sits where the compressed tree's boxes are conservative (SceneDev::origin_limit)
+    float ns_per_slot = 0.0f;                 // device time per path of the last pass that ran alone; 0 = not measured yet
     bool second_lane_for_short_passes = false; // lanes beyond the first take passes of at most kSmallPassSlots paths only
     bool overlap_connect = true;              // RT_HIP_OVERLAP_CONNECT=0 keeps every launch of a pass on one stream
     bool paths_ok = false;                    // path buffers match W x H (false after a resize that ran out of memory)
@@ -314,6 +321,12 @@ int clear_accum(rt_ctx* c) {
 
 // Camera rays start within the aperture around the camera location: are they where the compressed tree's boxes are
 // conservative? (Re-evaluated when the camera or the scene changes.)
+// The cost of a path depends on the scene, the camera and the resolution: forget the measurement when one of them changes.
+void forget_pass_cost(rt_ctx* c) {
+    c->ns_per_slot = 0.0f;
+    for (Lane& l : c->lanes) l.timed = false;
+}
+
 void update_camera_limit(rt_ctx* c) {
     const float reach = std::fabs(c->cam.aperture_radius);
     bool ok = true;
@@ -484,6 +497,8 @@ extern "C" int rt_create(const rt_config* cfg, rt_ctx** out) {
         if (se == hipSuccess) se = masked ? hipExtStreamCreateWithCUMask(&l.side, 8, cu_mask) : hipStreamCreateWithFlags(&l.side, hipStreamNonBlocking);
         if (se == hipSuccess) se = hipEventCreateWithFlags(&l.shaded, hipEventDisableTiming);
         if (se == hipSuccess) se = hipEventCreateWithFlags(&l.connected, hipEventDisableTiming);
+        if (se == hipSuccess) se = hipEventCreate(&l.t_begin);
+        if (se == hipSuccess) se = hipEventCreate(&l.t_end);
         if (se != hipSuccess || hipEventCreateWithFlags(&l.pass_done, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&l.consumed, hipEventDisableTiming) != hipSuccess) { c->err = "lane stream/event creation failed"; return bail(RT_ERR_DEVICE); }
     }
@@ -515,6 +530,8 @@ extern "C" void rt_destroy(rt_ctx* c) {
     for (Lane& l : c->lanes) {
         if (l.pass_done) (void)hipEventDestroy(l.pass_done);
         if (l.consumed) (void)hipEventDestroy(l.consumed);
+        if (l.t_begin) (void)hipEventDestroy(l.t_begin);
+        if (l.t_end) (void)hipEventDestroy(l.t_end);
         if (l.shaded) (void)hipEventDestroy(l.shaded);
         if (l.connected) (void)hipEventDestroy(l.connected);
         if (l.side) (void)hipStreamDestroy(l.side);
@@ -611,6 +628,7 @@ extern "C" int rt_upload_scene(rt_ctx* c, const void* blob, const uint64_t sizes
     sd.cdf_len_seen = std::max(1u, seen);
     c->have_scene = true;
     update_camera_limit(c);
+    forget_pass_cost(c);
     return clear_accum(c);
 }
 
@@ -754,6 +772,7 @@ extern "C" int rt_set_camera(rt_ctx* c, const rt_camera* cam) {
     refresh_camera(c);
     c->have_camera = true;
     update_camera_limit(c);
+    forget_pass_cost(c);
     return clear_accum(c);
 }
 
@@ -763,6 +782,7 @@ extern "C" int rt_resize(rt_ctx* c, uint32_t w, uint32_t h) {
     int rc;
     if ((rc = bind_device(c)) != RT_OK) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    forget_pass_cost(c);
     const uint32_t old_w = c->W, old_h = c->H;
     c->W = w; c->H = h; c->npix = w * h;
     c->paths_ok = false;
@@ -813,18 +833,42 @@ extern "C" int rt_render(rt_ctx* c, uint32_t n_samples) {
     // buffers hold (fewer, longer launches: less time in the ramp-down of each persistent traversal grid), short passes
     // alternate between lanes and overlap. With a fixed lane count (RT_HIP_LANES) every call is split into at least one
     // pass per lane.
-    const uint32_t min_passes = c->second_lane_for_short_passes ? 1u : std::min<uint32_t>(c->n_lanes, n_samples);
+    // How a long pass is scheduled depends on what a path costs here. Every traversal launch ends with a few waves walking
+    // its longest rays at memory latency (0.2-0.3 ms whatever the list size); where paths are cheap (open scenes whose paths
+    // leave early, tiny scenes) that run-down is a large share of the pass and a second concurrent pass fills it (+10 % on the
+    // 448k-triangle car under a sky, +7 % on the Cornell box at 1080p), where they are expensive it only evicts the first
+    // pass's tree from the caches (-4 % on the atrium). The device time of the last pass that ran alone decides.
+    for (uint32_t i = 0; i < c->n_lanes; ++i) {
+        Lane& l = c->lanes[i];
+        if (!l.timed || hipEventQuery(l.t_end) != hipSuccess) continue;
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, l.t_begin, l.t_end) == hipSuccess && l.timed_slots) c->ns_per_slot = ms * 1e6f / float(l.timed_slots);
+        l.timed = false;
+    }
+    (void)hipGetLastError();                                     // a pass still running reports "not ready": not an error
+    const bool cheap_paths = c->ns_per_slot > 0.0f && c->ns_per_slot < kCheapSlotNs;
+    const bool always_alternate = !c->second_lane_for_short_passes || (cheap_paths && c->n_lanes > 1);
+    const uint32_t min_passes = always_alternate ? std::min<uint32_t>(c->n_lanes, n_samples) : 1u;
     uint32_t n_pass = std::max<uint32_t>((n_samples + c->fpp - 1) / c->fpp, min_passes);
+    const bool single_pass_call = n_pass == 1;
     uint32_t left = n_samples;
     while (left) {
         uint32_t frames = (left + n_pass - 1) / n_pass;
         --n_pass;
         uint32_t frame_first = c->slice_first + c->local_frame * c->slice_stride;
-        const bool alternate = !c->second_lane_for_short_passes || uint64_t(frames) * c->npix <= kSmallPassSlots;
+        const bool alternate = always_alternate || uint64_t(frames) * c->npix <= kSmallPassSlots;
         Lane& l = c->lanes[alternate ? c->next_lane : 0];
         if (alternate) c->next_lane = (c->next_lane + 1) % c->n_lanes;
         if (l.busy) HIPCHK(c, hipStreamWaitEvent(l.stream, l.consumed, 0));   // its previous radiance has been accumulated
+        // time the pass when it has the machine to itself as far as can be known here: the only pass of its call, every
+        // other lane idle when it is queued
+        bool time_it = c->second_lane_for_short_passes && single_pass_call && l.t_begin != nullptr;
+        for (uint32_t i = 0; time_it && i < c->n_lanes; ++i)
+            if (&c->lanes[i] != &l && c->lanes[i].busy && hipEventQuery(c->lanes[i].pass_done) != hipSuccess) time_it = false;
+        (void)hipGetLastError();
+        if (time_it) HIPCHK(c, hipEventRecord(l.t_begin, l.stream));
         if ((rc = run_pass(c, l, l.stream, frames, frame_first, c->slice_stride, nullptr)) != RT_OK) return rc;
+        if (time_it) { HIPCHK(c, hipEventRecord(l.t_end, l.stream)); l.timed = true; l.timed_slots = uint64_t(frames) * c->npix; }
         HIPCHK(c, hipEventRecord(l.pass_done, l.stream));
         HIPCHK(c, hipStreamWaitEvent(c->stream, l.pass_done, 0));
         {
