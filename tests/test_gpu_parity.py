@@ -284,6 +284,25 @@ def test_tuning_the_resident_set_changes_no_result(rt, oracle, scene_cache, exac
     r.destroy()
 
 
+def test_tuning_degenerate_scenes_is_a_no_op(rt):
+    """A scene whose root is a leaf has no node records to order, and an empty scene has nothing at all: the call succeeds,
+    reports zeros and rendering goes on as before."""
+    from test_oracle import one_triangle_scene
+    from ray_tracer_amd.scene import Scene, default_material, look_at_camera
+    cam = look_at_camera(37, 23, (0, 0, 3), (0, 0, 0))
+    empty = Scene(triangles=np.zeros(0, rt.api.TRIANGLE), materials=default_material(1), camera=cam).finalize()
+    for sc in (one_triangle_scene(), empty, two_leaf_scene()):
+        r = rt.HipRenderer.create(sc, max_bounces=3)
+        r.render(2)
+        before = r.read_accum()
+        rep = r.tune_resident_set()
+        assert rep["records_moved"] == [0, 0, 0] or sum(rep["sampled_visits"]) > 0
+        r.reset_accumulator()
+        r.render(2)
+        assert np.array_equal(r.read_accum(), before, equal_nan=True)
+        r.destroy()
+
+
 def test_occlusion_tree_collapse_respects_boxes_that_are_not_nested(rt, oracle):
     """Occlusion queries walk a 4-wide tree collapsed from the binary one, which is exact only where a child's box lies
     inside its parent's. A hand-made tree whose grandchild box sticks out of its parent's box must not be collapsed there:
