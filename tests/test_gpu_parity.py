@@ -284,6 +284,34 @@ def test_tuning_the_resident_set_changes_no_result(rt, oracle, scene_cache, exac
     r.destroy()
 
 
+def test_stream_plan_matches_single_stream_over_call_patterns(rt, scene_cache):
+    """The default plan (shadow rays on a side stream, short or cheap passes alternating between two sets of path buffers,
+    lane choice following the measured cost of a path) against RT_SINGLE_STREAM, bit for bit, over random call patterns with
+    and without synchronisation, camera moves and resets in between: a race between the streams would show as a differing bit.
+    `tools/stream_plan_stress.py` is the long version."""
+    rng = np.random.default_rng(17)
+    for name, kw, bounces in (("atrium", dict(scale=0.05, width=192, height=108), 6), ("car", dict(scale=0.03, width=192, height=108), 6)):
+        sc = scene_cache(name, **kw)
+        a = rt.HipRenderer.create(sc, max_bounces=bounces)
+        b = rt.HipRenderer.create(sc, max_bounces=bounces, flags=rt.api.RT_SINGLE_STREAM)
+        for it in range(12):
+            pattern = [int(x) for x in rng.choice([1, 1, 2, 3, 5, 8, 13, 40], size=rng.integers(1, 5))]
+            sync_between = bool(rng.integers(0, 2))
+            if it % 4 == 3:
+                cam = sc.camera.copy()
+                cam["location"][0][:3] += rng.normal(scale=0.05, size=3).astype(np.float32)
+                a.set_camera(cam); b.set_camera(cam)
+            else:
+                a.reset_accumulator(); b.reset_accumulator()
+            for n in pattern:
+                a.render(n); b.render(n)
+                if sync_between:
+                    a.frame_complete(); b.frame_complete()
+            assert a.sample_count() == b.sample_count() == sum(pattern)
+            assert np.array_equal(a.read_accum(), b.read_accum(), equal_nan=True), (name, it, pattern, sync_between)
+        a.destroy(); b.destroy()
+
+
 def test_tuning_degenerate_scenes_is_a_no_op(rt):
     """A scene whose root is a leaf has no node records to order, and an empty scene has nothing at all: the call succeeds,
     reports zeros and rendering goes on as before."""
