@@ -58,6 +58,8 @@ def main(out, dst):
     res = {"source": os.path.basename(out.rstrip("/")), "bench_args": f"--steps {steps} --warmup {warm}", "launch_frames": steps,
            "workload": bench["config"]["workload"], "note": "per work item; fabric bytes include Infinity-Cache hits (upper bound on HBM bytes)"}
     for k in KERNELS:
+        if k not in da or not items[k]:        # a scene without lights launches no k_connect
+            continue
         n = items[k]
         cyc = c[k]["GRBM_GUI_ACTIVE"] / 8.0                     # summed over the pass's launches, per XCD
         res[k] = {
