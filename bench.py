@@ -174,6 +174,12 @@ def main():
 
     # ---- warm-up, then the timed region: exactly K steps (+ the accumulation reduce when N > 1)
     r.render(args.warmup)
+    if dist is not None:
+        # warm-up of the collective as well: the first all-reduce of a buffer of this size sets up RCCL's channels
+        import torch
+        r.frame_complete()
+        reduce_accumulators(red)
+        torch.cuda.synchronize()
     r.reset_accumulator()
     r.reset_counters()
     barrier()
