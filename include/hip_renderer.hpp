@@ -117,6 +117,9 @@ public:
     void reset_accumulator() { check(rt_reset_accumulation(ctx_), ctx_); }         // renderer.rs:170-177
     uint32_t sample_count() const { return rt_sample_count(ctx_); }                  // renderer.rs:180-182
     void handle_resize(uint32_t w, uint32_t h) { check(rt_resize(ctx_, w, h), ctx_); }   // renderer.rs:133-162
+    // No counterpart upstream: orders the node records by measured use for the scene and camera now installed, so the
+    // traversal kernels keep the busiest ones in LDS. Output bits do not change.
+    rt_tune_report tune_resident_set() { rt_tune_report rep{}; check(rt_tune_resident_set(ctx_, &rep), ctx_); return rep; }
     void set_frame_slice(uint32_t first, uint32_t stride) { check(rt_set_frame_slice(ctx_, first, stride), ctx_); }
     // dispatch_compute (renderer.rs:269-321): queues n samples, asynchronous.
     void dispatch_compute(uint32_t n_samples = 1) { check(rt_render(ctx_, n_samples), ctx_); }

@@ -36,6 +36,13 @@ int main() {
         std::vector<float> img(32 * 32 * 4);
         r.read_accum(img);
         if (r.sample_count() != 2 || !(img[(16 * 32 + 16) * 4] > 0.0f)) { std::puts("render produced nothing"); return 1; }
+        const rt_tune_report rep = r.tune_resident_set();            // the root is a leaf: nothing to move, and nothing changes
+        std::vector<float> again(32 * 32 * 4);
+        r.reset_accumulator();
+        r.dispatch_compute(2);
+        r.frame_complete();
+        r.read_accum(again);
+        if (rep.records_moved[0] != 0 || again != img) { std::puts("tuning changed the picture"); return 1; }
         std::puts("gpu render ok");
     } catch (const rt::Error& e) {
         if (e.code != RT_ERR_DEVICE) { std::printf("unexpected failure: %s\n", e.what()); return 1; }
