@@ -123,7 +123,8 @@ public:
     void set_frame_slice(uint32_t first, uint32_t stride) { check(rt_set_frame_slice(ctx_, first, stride), ctx_); }
     // dispatch_compute (renderer.rs:269-321): queues n samples, asynchronous.
     void dispatch_compute(uint32_t n_samples = 1) { check(rt_render(ctx_, n_samples), ctx_); }
-    void frame_complete() { check(rt_sync(ctx_), ctx_); }                              // renderer.rs:251-267
+    void frame_complete() { check(rt_sync(ctx_), ctx_); }                              // waits (headless use)
+    bool frame_done() { int d = 0; check(rt_poll(ctx_, &d), ctx_); return d != 0; }      // frame_complete as a fence status, renderer.rs:251-267
     void read_accum(std::vector<float>& rgba) { check(rt_read_accum_f32(ctx_, rgba.data(), rgba.size()), ctx_); }
     void read_framebuffer(std::vector<uint8_t>& rgba) { check(rt_read_framebuffer_rgba8(ctx_, rgba.data(), rgba.size()), ctx_); }
     rt_timings last_timer_perf() const { rt_timings t{}; check(rt_last_timings(ctx_, &t), ctx_); return t; }   // renderer.rs:239-248

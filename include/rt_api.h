@@ -261,8 +261,12 @@ int rt_set_frame_slice(rt_ctx* ctx, uint32_t first, uint32_t stride);
 /* n_samples x dispatch_compute (renderer.rs:269-321): each sample is one full path per pixel with the frame index
  * of its dispatch. Asynchronous: returns once the work is queued on the context's stream. */
 int rt_render(rt_ctx* ctx, uint32_t n_samples);
-/* Blocks until all queued work of the context has finished (frame_complete, renderer.rs:251-267). */
+/* Blocks until all queued work of the context has finished. */
 int rt_sync(rt_ctx* ctx);
+/* frame_complete (renderer.rs:251-267) asks a fence without waiting, so that the render loop can keep several dispatches in
+ * flight (render_controller.rs:233-244): *done = 1 when everything queued so far has finished, else 0. Never blocks and
+ * does not keep the next rt_render from overlapping the work still running. */
+int rt_poll(rt_ctx* ctx, int* done);
 /* sample_count (renderer.rs:180-182): samples accumulated by this context since the last reset. */
 uint32_t rt_sample_count(const rt_ctx* ctx);
 

@@ -44,7 +44,7 @@ fn main() -> Result<()> {
     );
     let start = Instant::now();
     renderer.dispatch_samples(spp)?; // one call: the library batches the samples into large wavefront passes
-    renderer.frame_complete(0)?;
+    renderer.wait_idle()?;
     let secs = start.elapsed().as_secs_f64();
     let (w, h) = renderer.render_resolution();
     log::info!("{spp} spp at {w}x{h} in {secs:.3} s ({:.1} samples/s)", spp as f64 / secs);

@@ -325,6 +325,7 @@ extern "C" {
     pub fn rt_set_frame_slice(ctx: *mut RtCtx, first: u32, stride: u32) -> i32;
     pub fn rt_render(ctx: *mut RtCtx, n_samples: u32) -> i32;
     pub fn rt_sync(ctx: *mut RtCtx) -> i32;
+    pub fn rt_poll(ctx: *mut RtCtx, done: *mut i32) -> i32;
     pub fn rt_sample_count(ctx: *const RtCtx) -> u32;
     pub fn rt_read_accum_f32(ctx: *mut RtCtx, rgba: *mut f32, n_floats: usize) -> i32;
     pub fn rt_read_sum_f32(ctx: *mut RtCtx, rgba: *mut f32, n_floats: usize) -> i32;

@@ -130,10 +130,17 @@ impl HipRenderer {
         check(unsafe { rt_render(self.ctx, n) }, self.ctx)
     }
 
-    /// frame_complete (renderer.rs:251-267)
+    /// frame_complete (renderer.rs:251-267): the fence status the render loop polls while it keeps dispatches in flight
+    /// (render_controller.rs:233-244). The library has one timeline, so every slot is done when all queued work is.
     pub fn frame_complete(&mut self, _slot: usize) -> Result<bool> {
-        check(unsafe { rt_sync(self.ctx) }, self.ctx)?;
-        Ok(true)
+        let mut done = 0i32;
+        check(unsafe { rt_poll(self.ctx, &mut done) }, self.ctx)?;
+        Ok(done != 0)
+    }
+
+    /// Blocks until everything queued has finished (headless use).
+    pub fn wait_idle(&mut self) -> Result<()> {
+        check(unsafe { rt_sync(self.ctx) }, self.ctx)
     }
 
     /// SaveFrame (renderer.rs:336-444; utils/save_frame.rs:27-65): the tone-mapped RGBA8 frame as a PNG.

@@ -131,6 +131,7 @@ API = {
     "rt_last_timings": (_I, [_P, _P]),
     "rt_get_counters": (_I, [_P, _P]),
     "rt_reset_counters": (_I, [_P]),
+    "rt_poll": (_I, [_P, _P]),
     "rt_tune_resident_set": (_I, [_P, _P]),
     "rt_trace_closest": (_I, [_P, _U32, _P, _P, _P]),
     "rt_trace_closest_static": (_I, [_P, _U32, _P, _P, _P]),

@@ -905,6 +905,20 @@ extern "C" int rt_sync(rt_ctx* c) {
     return RT_OK;
 }
 
+extern "C" int rt_poll(rt_ctx* c, int* done) {
+    if (!c) return RT_ERR_INVALID;
+    if (!done) return fail(c, RT_ERR_INVALID, "rt_poll: null output");
+    const bool must_wait = c->lanes_must_wait;
+    int rc;
+    if ((rc = bind_device(c)) != RT_OK) return rc;
+    c->lanes_must_wait = must_wait;                              // asking queues nothing
+    const hipError_t e = hipStreamQuery(c->stream);              // every pass is followed by its accumulation on the main stream
+    if (e != hipSuccess && e != hipErrorNotReady) HIPCHK(c, e);
+    (void)hipGetLastError();
+    *done = e == hipSuccess ? 1 : 0;
+    return RT_OK;
+}
+
 extern "C" uint32_t rt_sample_count(const rt_ctx* c) { return c ? c->local_frame : 0; }
 
 extern "C" int rt_read_sum_f32(rt_ctx* c, float* rgba, size_t n_floats) {

@@ -126,6 +126,13 @@ class HipRenderer:
     def frame_complete(self):
         self._check(self.lib.rt_sync(self._ctx))
 
+    # frame_complete as the reference's render loop uses it (renderer.rs:251-267, render_controller.rs:233-244): a fence
+    # status, not a wait
+    def frame_done(self) -> bool:
+        done = C.c_int(0)
+        self._check(self.lib.rt_poll(self._ctx, C.byref(done)))
+        return bool(done.value)
+
     def render(self, n_samples: int):
         self.dispatch_compute(n_samples)
         self.frame_complete()

@@ -312,6 +312,31 @@ def test_stream_plan_matches_single_stream_over_call_patterns(rt, scene_cache):
         a.destroy(); b.destroy()
 
 
+def test_render_loop_with_polled_completion(rt, scene_cache):
+    """The reference's loop keeps several dispatches in flight and polls `frame_complete` (a fence status,
+    renderer.rs:251-267, render_controller.rs:233-244). Driven that way (one sample per dispatch, never blocking, polling in
+    between), the accumulated image equals one 24-sample call bit for bit, the poll turns true once the work has drained and
+    is true on an idle context."""
+    import time
+    sc = scene_cache("atrium", scale=0.05, width=192, height=108)
+    a = rt.HipRenderer.create(sc, max_bounces=6)
+    b = rt.HipRenderer.create(sc, max_bounces=6)
+    a.frame_complete()
+    assert a.frame_done()                                       # idle: the uploads and clears of create() have drained
+    polls = 0
+    for _ in range(24):
+        a.dispatch_compute(1)
+        polls += int(a.frame_done())                            # may or may not have finished: must not block or disturb
+    deadline = time.time() + 30.0
+    while not a.frame_done():
+        assert time.time() < deadline, "work never drained"
+        time.sleep(0.001)
+    assert a.sample_count() == 24
+    b.render(24)
+    assert np.array_equal(a.read_accum(), b.read_accum(), equal_nan=True)
+    a.destroy(); b.destroy()
+
+
 def test_tuning_degenerate_scenes_is_a_no_op(rt):
     """A scene whose root is a leaf has no node records to order, and an empty scene has nothing at all: the call succeeds,
     reports zeros and rendering goes on as before."""

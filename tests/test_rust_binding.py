@@ -175,7 +175,7 @@ def test_headless_binary_uses_only_methods_the_facade_has():
                for m in re.finditer(r"pub fn (\w+)\s*\(([^)]*)\)", rend)}
     src = re.sub(r"//.*", "", (RUST.parent / "bin" / "headless.rs").read_text())
     calls = re.findall(r"\brenderer\.(\w+)\s*\(([^()]*)\)", src) + re.findall(r"\bHipRenderer::(\w+)\s*\(([^()]*)\)", src)
-    assert {c[0] for c in calls} >= {"create", "dispatch_samples", "frame_complete", "save_frame", "tune_resident_set"}
+    assert {c[0] for c in calls} >= {"create", "dispatch_samples", "wait_idle", "save_frame", "tune_resident_set"}
     for name, args in calls:
         assert name in methods, name
         n_args = len([a for a in args.split(",") if a.strip()])
