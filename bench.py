@@ -53,7 +53,7 @@ def algorithmic_bytes_extend(rays, node_pops, tri_tests):
 
 def algorithmic_bytes_connect(rays, node_pops, tri_tests, wide):
     # per shadow ray: 32 B ray + 16 B queued contribution in, 4 B result, 32 B root node; per node visit two 32-B child boxes,
-    # or four 24-B boxes + four references (112 B) when the occlusion queries walk the 4-wide tree (scenes without glass)
+    # or four 24-B boxes + four references (112 B) when the occlusion queries walk the uncompressed 4-wide tree (exact-order mode, scenes without glass)
     return rays * (32 + 16 + 4 + 32) + node_pops * (112 if wide else 64) + tri_tests * 48
 
 
@@ -259,7 +259,8 @@ def main():
                        and args.frames_per_pass == 0 and args.bvh == "spatial")
         if default_cfg and pfile.exists():
             prof = json.loads(pfile.read_text())
-        wide = not bool((scene.materials["spec_trans"] > 0.5).any())
+        any_hit = not bool((scene.materials["spec_trans"] > 0.5).any())      # shadow rays may stop at the first hit
+        wide = any_hit and args.exact_order                                   # 112-byte records only under RT_EXACT_ORDER
         items = {"k_extend": c["extend_rays"], "k_shade": c["extend_rays"], "k_connect": c["shadow_rays"]}
         ms = {"k_extend": tm["extend_ms"], "k_shade": tm["shade_ms"], "k_connect": tm["connect_ms"]}
         launches = {"k_extend": tm["extend_launches"], "k_shade": tm["shade_launches"], "k_connect": tm["connect_launches"]}
@@ -317,7 +318,7 @@ def main():
         result["kernel_ms_per_sample"] = {s_: tm[f"{s_}_ms"] / k for s_ in ("raygen", "extend", "shade", "connect", "accumulate")}
         result["kernel_ms_per_sample"]["total"] = tm["total_ms"] / k
         result["connect"] = {"mrays_per_s": per_kernel["k_connect"]["mitems_per_s"],
-                             "tree": "4-wide (any-hit)" if wide else "compressed 4-wide (closest hit, glass rule)",
+                             "tree": ("4-wide" if wide else ("binary" if args.exact_order else "compressed 4-wide")) + (", any hit" if any_hit else ", closest hit (glass rule)"),
                              "node_pops_per_ray": c["shadow_node_pops"] / max(1, c["shadow_rays"]),
                              "tri_tests_per_ray": c["shadow_tri_tests"] / max(1, c["shadow_rays"])}
 

@@ -50,7 +50,9 @@ enum {
                                        4-wide tree with conservative boxes, about 1.25x faster in that kernel: distances and ids still
                                        equal the shader's except where two triangles lie within rounding distance of
                                        each other along the ray (either may be reported), or where the shader's own box
-                                       test loses a hit to rounding (the hit is then reported).                       */
+                                       test loses a hit to rounding (the hit is then reported). Shadow rays follow the
+                                       same rule: blocked whenever the shader says blocked, up to blockers within
+                                       rounding distance of the light.                                            */
     RT_SINGLE_STREAM     = 1u << 5  /* every kernel of every pass on one stream, one after another. By default the
                                        shadow rays of a bounce run on a side stream beside the next bounce's closest-hit
                                        search, and short passes (up to 24 Mi paths, 12 frames of 1080p) alternate between

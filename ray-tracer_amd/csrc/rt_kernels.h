@@ -585,7 +585,7 @@ RT_DEV void leaf_phase(const SceneDev& sc, LaneRay& r, unsigned long long parked
 // ANYHIT turns the closest-hit search into an occlusion query (stop at the first hit below tmax).
 //   void store(uint32_t handle, const LaneRay& r)
 // TREE: which tree is walked. kTreeBinary: the reference's binary tree in the reference's order (bit-identical ids).
-// kTreeWide (occlusion queries only): the uncompressed 4-wide tree, exact for order-independent queries.
+// kTreeWide (occlusion queries under RT_EXACT_ORDER only): the uncompressed 4-wide tree, the reference's box arithmetic.
 // kTreeCw: the compressed 4-wide tree, conservative boxes (see cw_step).
 constexpr int kTreeBinary = 0, kTreeWide = 1, kTreeCw = 2;
 template <bool COUNT, bool ANYHIT, int TREE, class Work>
@@ -853,10 +853,12 @@ __global__ __launch_bounds__(kTraceBlock, RT_TRACE_WAVES_PER_EU) void k_extend(S
 template <bool COUNT, bool ANYHIT, bool FAST>
 __global__ __launch_bounds__(kTraceBlock, RT_TRACE_WAVES_PER_EU) void k_connect(SceneDev sc, ShadowDev sq, float4* __restrict__ rad, Regions rg,
                                                     uint32_t* cursor, TraceStats* stats) {
-    // Occlusion queries that may stop at the first hit walk the uncompressed 4-wide tree in either mode: it is exact for them
-    // (their answer does not depend on visiting order) and measured faster than the compressed one (0.69 vs 0.73 ms per
-    // sample on the 1080p atrium), whose nearest-first ordering buys an any-hit query nothing.
-    constexpr int TREE = ANYHIT ? kTreeWide : (FAST ? kTreeCw : kTreeBinary);
+    // By default every query walks the compressed tree: an occlusion query that may stop at the first hit finds a blocker
+    // below tmax whenever the reference does (the compressed boxes contain the reference's), whatever the visiting order, and
+    // the 64-byte records cost it less than the 112-byte ones of the uncompressed 4-wide tree (0.666 -> 0.637 ms per sample
+    // on the 1080p atrium). Under RT_EXACT_ORDER such queries use the uncompressed 4-wide tree, which reproduces the
+    // reference's box arithmetic, and closest-hit queries (scenes with glass) the binary tree.
+    constexpr int TREE = FAST ? kTreeCw : (ANYHIT ? kTreeWide : kTreeBinary);
     RT_TRACE_LDS(TREE)
     const uint32_t n = load_region_prefix(rg, s_prefix);
     uint32_t n_node = 0, n_leaf = 0, n_tri = 0;
@@ -1306,13 +1308,14 @@ __global__ __launch_bounds__(kTraceBlock, RT_TRACE_WAVES_PER_EU) void k_trace_ra
                                                        uint32_t n, int shadow, float4* __restrict__ hits, uint32_t* cursor,
                                                        TraceStats* stats) {
     const bool any_hit = shadow && !sc.has_glass;       // wave-uniform
-    const int tree = any_hit ? kTreeWide : (FAST ? kTreeCw : kTreeBinary);
+    const int tree = FAST ? kTreeCw : (any_hit ? kTreeWide : kTreeBinary);
     RT_TRACE_LDS(tree)
     uint32_t n_node = 0, n_leaf = 0, n_tri = 0;
     RayListWork work{sc, ro, rd, hits, shadow};
     lds_u32* st = (lds_u32*)s_stack + threadIdx.x;
     lds_u8* ow = (lds_u8*)s_owner + (threadIdx.x & ~63u);
-    if (any_hit) trace_persistent<COUNT, true, kTreeWide>(sc, work, n, cursor, st, ow, hot, n_node, n_leaf, n_tri);
+    if (any_hit && FAST) trace_persistent<COUNT, true, kTreeCw>(sc, work, n, cursor, st, ow, hot, n_node, n_leaf, n_tri);
+    else if (any_hit) trace_persistent<COUNT, true, kTreeWide>(sc, work, n, cursor, st, ow, hot, n_node, n_leaf, n_tri);
     else if (FAST) trace_persistent<COUNT, false, kTreeCw>(sc, work, n, cursor, st, ow, hot, n_node, n_leaf, n_tri);
     else trace_persistent<COUNT, false, kTreeBinary>(sc, work, n, cursor, st, ow, hot, n_node, n_leaf, n_tri);
     if (shadow) flush_counts<COUNT>(n_node, n_leaf, n_tri, &stats->shadow_node_pops, &stats->shadow_leaf_pops, &stats->shadow_tri_tests);
