@@ -45,7 +45,7 @@ constexpr uint32_t kTraceBlock = RT_TRACE_BLOCK;   // workgroup size of the trav
 #define RT_COOP_ANYHIT 0
 #endif
 #ifndef RT_LEAF_BATCH
-#define RT_LEAF_BATCH 12
+#define RT_LEAF_BATCH 16
 #endif
 #ifndef RT_HOT_LDS
 #define RT_HOT_LDS 746
