@@ -341,27 +341,24 @@ RT_DEV f3 disney_sample(const Mat& m, const ShadePoint& sp, float r1, float r2, 
         f3 H = normalize(L + V);
         f = eval_diffuse(m, sp.sheen_col, V, L, H, out_pdf);
         out_pdf *= w.diffuse;
-    } else if (r1 < c1) {
-        r1 = (r1 - c0) / (c1 - c0);
-        f3 H = sample_ggx_vndf(V, m.roughness, r1, r2);
-        if (H.z < 0.0f) H = -H;
-        L = normalize(reflect3(-V, H));
-        f = eval_spec_reflection(m, sp.eta, sp.spec_col, V, L, H, out_pdf);
-        out_pdf *= w.refl;
-    } else if (r1 < c2) {
-        r1 = (r1 - c1) / (c2 - c1);
-        f3 H = sample_ggx_vndf(V, m.roughness, r1, r2);
-        if (H.z < 0.0f) H = -H;
-        L = normalize(refract3(-V, H, sp.eta));
-        f = eval_spec_refraction(m, sp.eta, V, L, H, out_pdf);
-        out_pdf *= w.refr;
     } else {
-        r1 = (r1 - c2) / (1.0f - c2);
-        f3 H = sample_gtr1(m.clearcoat_roughness, r1);
+        // The three specular lobes, each lane taking the branch the shader takes (disney.comp:499-552) with the shader's
+        // arithmetic; what they share is written once so that a wavefront whose lanes picked different lobes runs it once:
+        // the rescaling of r1, the GGX half-vector of reflection and refraction, the mirror direction of reflection and
+        // clearcoat.
+        const int lobe = r1 < c1 ? 1 : (r1 < c2 ? 2 : 3);
+        const float lo = lobe == 1 ? c0 : (lobe == 2 ? c1 : c2);
+        const float hi = lobe == 1 ? c1 : (lobe == 2 ? c2 : 1.0f);
+        r1 = (r1 - lo) / (hi - lo);
+        f3 H;
+        if (lobe != 3) H = sample_ggx_vndf(V, m.roughness, r1, r2);
+        else H = sample_gtr1(m.clearcoat_roughness, r1);
         if (H.z < 0.0f) H = -H;
-        L = normalize(reflect3(-V, H));
-        f = eval_clearcoat(m, V, L, H, out_pdf);
-        out_pdf *= w.coat;
+        if (lobe != 2) L = normalize(reflect3(-V, H));
+        else L = normalize(refract3(-V, H, sp.eta));
+        if (lobe == 1) { f = eval_spec_reflection(m, sp.eta, sp.spec_col, V, L, H, out_pdf); out_pdf *= w.refl; }
+        else if (lobe == 2) { f = eval_spec_refraction(m, sp.eta, V, L, H, out_pdf); out_pdf *= w.refr; }
+        else { f = eval_clearcoat(m, V, L, H, out_pdf); out_pdf *= w.coat; }
     }
     Lworld = to_world(sp, L);
     return f * fabsf(dot(sp.N, Lworld));
