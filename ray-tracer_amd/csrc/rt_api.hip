@@ -138,7 +138,8 @@ struct rt_ctx {
     uint32_t slice_first = 0, slice_stride = 1;
     rt_camera cam{};
     bool have_scene = false, have_camera = false;
-    bool fast = true;                         // walk the compressed 4-wide tree (false: RT_EXACT_ORDER)
+    bool fast_requested = true;               // the caller did not ask for RT_EXACT_ORDER
+    bool fast = true;                         // walk the compressed 4-wide tree (false: RT_EXACT_ORDER, or a scene the compressed tree cannot hold)
     bool camera_within_limit = true;          // the camera sits where the compressed tree's boxes are conservative (SceneDev::origin_limit)
     bool lanes_must_wait = true;              // something other than rt_render has used the main stream since the last pass was queued
     float ns_per_slot = 0.0f;                 // device time per path of the last pass that ran alone; 0 = not measured yet
@@ -454,7 +455,8 @@ extern "C" int rt_create(const rt_config* cfg, rt_ctx** out) {
     c->device = cfg->device;
     c->W = cfg->width; c->H = cfg->height; c->npix = cfg->width * cfg->height;
     c->max_bounces = mb; c->flags = cfg->flags; c->fpp_cfg = cfg->frames_per_pass;
-    c->fast = (cfg->flags & RT_EXACT_ORDER) == 0;
+    c->fast_requested = (cfg->flags & RT_EXACT_ORDER) == 0;
+    c->fast = c->fast_requested;
     auto bail = [&](int code) { std::string m = c->err; rt_destroy(c); fail(nullptr, code, m); return code; };
     if (uint64_t(cfg->width) * cfg->height > 0x7FFFFFFFull) { c->err = "resolution too large"; return bail(RT_ERR_UNSUPPORTED); }
     int rc;
@@ -623,6 +625,7 @@ extern "C" int rt_upload_scene(rt_ctx* c, const void* blob, const uint64_t sizes
     sd.n_hot_wide = gs.n_hot_wide;
     sd.cw = c->cw.as<float4>();
     sd.origin_limit = 30.0f * gs.scene_size;
+    c->fast = c->fast_requested && gs.cw_complete;
     sd.root_ref = gs.root_ref; sd.n_hot = gs.n_hot; sd.n_tri = n_tri; sd.n_light = n_light; sd.n_emissive = n_emissive; sd.n_mat = n_mat;
     // The shader sizes the CDF from its 16-byte padded binding; an empty table is bound as one dummy word
     // (src/vulkan/path_tracer/descriptors.rs:85-93).

@@ -98,6 +98,7 @@ struct GpuScene {
     std::vector<NodeCw> cw;      // compressed twin of `wide`, record for record
     float scene_size = 0.0f;     // largest absolute coordinate of the root bounds
     float box_margin = 0.0f;     // every compressed box contains its source box grown by this much: 2^-17 * scene_size
+    bool cw_complete = true;     // false when a box with an infinite bound could not be represented: the compressed tree must not be used
     std::vector<TriIsect> isect;
     std::vector<TriShade> shade;
 };

@@ -303,8 +303,13 @@ int convert_scene(const rt_bvh_node* nodes, uint32_t n_nodes, const rt_triangle*
             bool usable[4];
             for (int k = 0; k < 4; ++k) {
                 usable[k] = q.ref[k] != kRefNone;
-                for (int a = 0; a < 3 && usable[k]; ++a)       // NaN or inverted bounds are never entered by the reference's slab test
-                    usable[k] = std::isfinite(q.box[k][a]) && std::isfinite(q.box[k][3 + a]) && q.box[k][a] <= q.box[k][3 + a];
+                for (int a = 0; a < 3 && usable[k]; ++a) {     // NaN or inverted bounds are never entered by the reference's slab test
+                    const float lo = q.box[k][a], hi = q.box[k][3 + a];
+                    usable[k] = std::isfinite(lo) && std::isfinite(hi) && lo <= hi;
+                    // ... but a box that reaches to infinity is (a triangle with an infinite coordinate shares its leaf and its
+                    // ancestors with ordinary ones): 8-bit offsets cannot express it, so such a scene keeps the exact traversal
+                    if (!usable[k] && !std::isnan(lo) && !std::isnan(hi) && lo <= hi) out.cw_complete = false;
+                }
                 w.ref[k] = usable[k] ? q.ref[k] : kRefNone;
             }
             uint32_t lo_w[3] = {0, 0, 0}, hi_w[3] = {0, 0, 0};

@@ -134,6 +134,49 @@ def test_axis_parallel_and_non_finite_rays(rt, oracle, scene_cache):
     r.destroy()
 
 
+@pytest.mark.parametrize("kind", ["zero_area", "points", "huge", "nan", "inf", "same", "flat"])
+def test_degenerate_geometry_in_both_modes(rt, kind):
+    """Triangle soups with zero-area, point-like, 1e30-sized, NaN, infinite, identical or coplanar triangles: both traversal
+    modes terminate, render finite images and report the same hits up to eps-ties (the default may also find hits the
+    reference's box test loses). A scene with an infinite coordinate keeps the exact traversal: 8-bit box offsets cannot
+    express a box that reaches to infinity, and dropping it would lose the ordinary triangles that share its subtree.
+    `tools/degenerate_scene_fuzz.py` is the wide version (all builders, more kinds and sizes)."""
+    from ray_tracer_amd.scene import Scene, default_material, look_at_camera, make_triangles
+    rng = np.random.default_rng(5)
+    cam = look_at_camera(48, 48, (0, 0, 6), (0, 0, 0))
+    for n, spatial in ((65, False), (3000, True)):
+        v = rng.normal(size=(n, 3, 3)).astype(np.float32)
+        if kind == "zero_area": v[::3, 1] = v[::3, 0]
+        if kind == "points": v[:, 1] = v[:, 0]; v[:, 2] = v[:, 0]
+        if kind == "huge": v[::5] *= 1e30
+        if kind == "nan": v[::7, 0, 0] = np.nan
+        if kind == "inf": v[::7, 1, 1] = np.inf
+        if kind == "same": v[:] = v[0]
+        if kind == "flat": v[..., 2] = 0
+        mats = default_material(2)
+        mats["emission"][1][:3] = (5, 5, 5)
+        with np.errstate(all="ignore"):
+            sc = Scene(triangles=make_triangles(v, None, None, (np.arange(n) % 17 == 0).astype(np.uint32)), materials=mats, camera=cam)
+            sc.build_bvh(spatial=spatial).build_lights()
+        a = rt.HipRenderer.create(sc, max_bounces=4)
+        b = rt.HipRenderer.create(sc, max_bounces=4, flags=rt.api.RT_EXACT_ORDER)
+        o = (rng.normal(size=(4000, 3)) * 3).astype(np.float32)
+        d = rng.normal(size=(4000, 3)).astype(np.float32)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        g, h = a.trace_closest(o, d), b.trace_closest(o, d)
+        hit_g, hit_h = g["prim"] != 0xFFFFFFFF, h["prim"] != 0xFFFFFFFF
+        with np.errstate(all="ignore"):
+            tie = hit_g & hit_h & (np.abs(g["t"].astype(np.float64) - h["t"]) <= 1e-6 * np.abs(h["t"].astype(np.float64)))
+        differ = g["prim"] != h["prim"]
+        recovered = hit_g & (~hit_h | (g["t"] < h["t"]))
+        assert not (differ & ~tie & ~recovered).any(), (kind, n, int((differ & ~tie & ~recovered).sum()))
+        if kind == "inf":
+            assert np.array_equal(g["prim"], h["prim"])          # the exact traversal on both sides
+        a.render(3); b.render(3)
+        assert np.isfinite(a.read_accum()).all() and np.isfinite(b.read_accum()).all()
+        a.destroy(); b.destroy()
+
+
 def test_rays_from_far_outside_take_the_exact_box_test(rt, oracle, scene_cache):
     """The compressed boxes are padded for rays that start within 30 scene sizes of the origin. Rays from farther away (a
     camera 1000 scene sizes out, or caller-supplied rays) are traced with the reference's box arithmetic instead, so the
