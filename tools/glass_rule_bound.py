@@ -1,3 +1,4 @@
+"""What the shadow rule 'closest hit is glass => unoccluded' costs: renders the scenes that hold glass-like materials as they are (closest-hit shadow rays) and with spec_trans capped at 0.5 (shadow rays may stop at the first hit), and prints visits per shadow ray and per-kernel times (GPU box)."""
 import sys, time
 sys.path.insert(0, "/root/repo")
 import numpy as np

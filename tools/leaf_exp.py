@@ -1,3 +1,4 @@
+"""Leaf size against traversal cost on the atrium: builds the tree with min_leaf 2, 3, 4 and 6 and prints nodes, SAH cost, node visits and triangle tests per ray and per-kernel time (GPU box)."""
 import sys, time
 sys.path.insert(0,'/root/repo')
 import ray_tracer_amd as rt

@@ -1,3 +1,4 @@
+"""Lane utilisation of the closest-hit kernel from its counters, for a library built with -DRT_OCCUPANCY_PROBE (the leaf and triangle counters then count wave-level node steps and leaf phases): lanes per node step, node steps per leaf phase (GPU box)."""
 import sys; sys.path.insert(0,'.')
 import ray_tracer_amd as rt
 from ray_tracer_amd import scenes, api
