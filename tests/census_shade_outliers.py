@@ -1,4 +1,5 @@
-"""Census of the shade-stage differences between the HIP kernel and the CPU oracle, vertex by vertex (GPU box)."""
+"""Census of the shade-stage differences between the HIP kernel and the CPU oracle, vertex by vertex (GPU box). Not a test
+(pytest does not collect it): run it by name, `python tests/census_shade_outliers.py`."""
 import sys
 from pathlib import Path
 import numpy as np
