@@ -68,11 +68,20 @@ def main():
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    # RT_BENCH_REHEARSE_ONE_GPU=1: every rank uses GPU 0 and the collectives go through gloo, so that the N > 1 code path
+    # (rank environment, frame slices, barrier, max-over-ranks clock, the reduce, one JSON line from rank 0) can be run end to
+    # end on a box with a single GPU. The line it prints carries "rehearsal" and is not a measurement.
+    rehearse = os.environ.get("RT_BENCH_REHEARSE_ONE_GPU") == "1"
     if "RANK" in os.environ and "MASTER_ADDR" in os.environ:   # launched by torch.distributed.run (any world size)
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     elif n_gpus > 1:
         print("bench.py: --gpus > 1 needs torch.distributed.run (one rank per GPU)", file=sys.stderr)
         sys.exit(2)
@@ -230,6 +239,8 @@ def main():
         "mpaths_per_sec": world * args.steps * npix / elapsed / 1e6,
         "scene_build_s": t_scene, "bvh_build_ms": scene.bvh_stats.get("build_ms"), "bvh_build_bench": bvh_bench,
     }
+    if rehearse and world > 1:
+        result["rehearsal"] = f"{world} ranks sharing GPU 0, collectives over gloo: exercises the N > 1 code path, not a measurement"
 
     # ---- per-kernel resource fractions, rank 0 only. Times are measured live (HIP events around every launch, on the stream
     # the kernels run on, in a context that runs one pass of the size the timed region used); rays / vertices per launch come
