@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--exact-order", action="store_true", help="RT_EXACT_ORDER: the reference's tree and visiting order (bit-exact ids) instead of the default compressed 4-wide tree")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--frames-per-pass", type=int, default=0)
+    ap.add_argument("--partition", choices=("samples", "tiles"), default="samples",
+                    help="N > 1: samples = every rank renders whole frames of its own frame indices (per-GPU work fixed: weak scaling); "
+                         "tiles = every rank renders its 8x8 tiles of the same frames (total work fixed: strong scaling, bit-identical to one GPU)")
     ap.add_argument("--bvh", choices=("spatial", "object"), default="spatial",
                     help="split policy of the host BVH build; spatial = BinSah::spatial(), what Scene::build_bvh uses upstream")
     return ap.parse_args()
@@ -164,8 +167,12 @@ def main():
 
     note("scene and build-time baseline done; creating the renderer")
     r = rt.HipRenderer.create(scene, max_bounces=args.bounces, device=local_rank, frames_per_pass=args.frames_per_pass, flags=base_flags)
-    from ray_tracer_amd.distributed import frame_slice
-    r.set_frame_slice(*frame_slice(rank, world))
+    from ray_tracer_amd.distributed import frame_slice, tile_slice
+    if args.partition == "tiles":
+        r.set_tile_slice(*tile_slice(rank, world))
+    else:
+        r.set_frame_slice(*frame_slice(rank, world))
+    frames_total = args.steps if args.partition == "tiles" else world * args.steps     # distinct samples per pixel in the reduced image
     npix = args.width * args.height
 
     red = None
@@ -224,19 +231,20 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed * 1e3 / args.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if args.partition == "tiles" and world > 1 else "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"{scene.name} {args.width}x{args.height}, {args.bounces} bounces, NEE+MIS, 1 spp per step per GPU",
                    "triangles": int(len(scene.triangles)), "bvh_nodes": int(len(scene.bvh)), "emissive_tris": int(len(scene.emissive_tris)),
                    "bvh": f"binned SAH, {args.bvh} splits", "duplicated_triangles": int(scene.bvh_stats.get("duplicated_refs", 0)),
-                   "parallelism": f"sample-slice x{world}" if world > 1 else "single GPU", "frames_per_pass": int(args.frames_per_pass)},
-        "samples_per_sec": world * args.steps / elapsed,
-        "samples_per_sec_vs_rtx3080_readme_5_to_10": [world * args.steps / elapsed / 10.0, world * args.steps / elapsed / 5.0],
+                   "parallelism": (f"tile-slice x{world}" if args.partition == "tiles" else f"sample-slice x{world}") if world > 1 else "single GPU",
+                   "frames_per_pass": int(args.frames_per_pass)},
+        "samples_per_sec": frames_total / elapsed,
+        "samples_per_sec_vs_rtx3080_readme_5_to_10": [frames_total / elapsed / 10.0, frames_total / elapsed / 5.0],
         "value_div_8": rays_total / elapsed / 1e6 / 8.0,
         "extend_rays": ext_total, "shadow_rays": sh_total,
-        "mpaths_per_sec": world * args.steps * npix / elapsed / 1e6,
+        "mpaths_per_sec": frames_total * npix / elapsed / 1e6,
         "scene_build_s": t_scene, "bvh_build_ms": scene.bvh_stats.get("build_ms"), "bvh_build_bench": bvh_bench,
     }
     if rehearse and world > 1:

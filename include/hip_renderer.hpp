@@ -121,6 +121,7 @@ public:
     // traversal kernels keep the busiest ones in LDS. Output bits do not change.
     rt_tune_report tune_resident_set() { rt_tune_report rep{}; check(rt_tune_resident_set(ctx_, &rep), ctx_); return rep; }
     void set_frame_slice(uint32_t first, uint32_t stride) { check(rt_set_frame_slice(ctx_, first, stride), ctx_); }
+    void set_tile_slice(uint32_t first, uint32_t stride) { check(rt_set_tile_slice(ctx_, first, stride), ctx_); }
     // dispatch_compute (renderer.rs:269-321): queues n samples, asynchronous.
     void dispatch_compute(uint32_t n_samples = 1) { check(rt_render(ctx_, n_samples), ctx_); }
     void frame_complete() { check(rt_sync(ctx_), ctx_); }                              // waits (headless use)

@@ -259,6 +259,13 @@ int rt_reset_accumulation(rt_ctx* ctx);
  * The per-pixel seed uses the global index (main.comp:251), so the union over all slices equals a 1-GPU run.
  * Restarts accumulation. Default (0,1). No counterpart upstream (single GPU). */
 int rt_set_frame_slice(rt_ctx* ctx, uint32_t first, uint32_t stride);
+/* Multi-GPU tile slicing, the other partition of the same job: the image is cut into 8x8-pixel tiles (the footprint of one
+ * workgroup of the reference's dispatch, main.comp:13; path_tracer/mod.rs:332-337 launches ceil(w/8) x ceil(h/8) of them),
+ * numbered row by row, and this context renders tiles first, first+stride, ... of every frame; the other pixels of its
+ * accumulator stay zero (sum and sample count). Every pixel is then rendered by exactly one context with the seeds and in the
+ * order of a 1-GPU run, so the sum over all slices EQUALS the 1-GPU accumulator bit for bit. first < stride; default (0,1) =
+ * the whole image. Restarts accumulation. Independent of rt_set_frame_slice. No counterpart upstream (single GPU). */
+int rt_set_tile_slice(rt_ctx* ctx, uint32_t first, uint32_t stride);
 
 /* n_samples x dispatch_compute (renderer.rs:269-321): each sample is one full path per pixel with the frame index
  * of its dispatch. Asynchronous: returns once the work is queued on the context's stream. */

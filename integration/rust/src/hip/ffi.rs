@@ -323,6 +323,7 @@ extern "C" {
     pub fn rt_resize(ctx: *mut RtCtx, width: u32, height: u32) -> i32;
     pub fn rt_reset_accumulation(ctx: *mut RtCtx) -> i32;
     pub fn rt_set_frame_slice(ctx: *mut RtCtx, first: u32, stride: u32) -> i32;
+    pub fn rt_set_tile_slice(ctx: *mut RtCtx, first: u32, stride: u32) -> i32;
     pub fn rt_render(ctx: *mut RtCtx, n_samples: u32) -> i32;
     pub fn rt_sync(ctx: *mut RtCtx) -> i32;
     pub fn rt_poll(ctx: *mut RtCtx, done: *mut i32) -> i32;

@@ -177,6 +177,11 @@ impl HipRenderer {
     pub fn set_frame_slice(&mut self, first: u32, stride: u32) -> Result<()> {
         check(unsafe { rt_set_frame_slice(self.ctx, first, stride) }, self.ctx)
     }
+
+    /// Multi-GPU, the other partition: this renderer takes the 8x8 tiles first, first + stride, ... of every frame.
+    pub fn set_tile_slice(&mut self, first: u32, stride: u32) -> Result<()> {
+        check(unsafe { rt_set_tile_slice(self.ctx, first, stride) }, self.ctx)
+    }
 }
 
 /// destroy (renderer.rs:493-507)

@@ -120,6 +120,7 @@ API = {
     "rt_resize": (_I, [_P, _U32, _U32]),
     "rt_reset_accumulation": (_I, [_P]),
     "rt_set_frame_slice": (_I, [_P, _U32, _U32]),
+    "rt_set_tile_slice": (_I, [_P, _U32, _U32]),
     "rt_render": (_I, [_P, _U32]),
     "rt_sync": (_I, [_P]),
     "rt_sample_count": (_U32, [_P]),

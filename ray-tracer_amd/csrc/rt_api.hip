@@ -136,6 +136,7 @@ struct rt_ctx {
     uint32_t max_bounces = 24, flags = 0, fpp_cfg = 0, fpp = 1;
     uint32_t local_frame = 0;                 // samples issued by this context since the last reset
     uint32_t slice_first = 0, slice_stride = 1;
+    uint32_t tile_first = 0, tile_stride = 1; // rt_set_tile_slice: which 8x8 tiles of the image this context renders (1 = all)
     rt_camera cam{};
     bool have_scene = false, have_camera = false;
     bool fast_requested = true;               // the caller did not ask for RT_EXACT_ORDER
@@ -176,6 +177,24 @@ struct rt_ctx {
 
     uint32_t* aux_cursor() const { return lanes[0].aux_cursor(); }
     TraceStats* tstats() const { return stats.as<TraceStats>(); }
+    // the tile slice as the kernels take it, the local pixels per frame it makes (64 per owned tile, overhanging ones
+    // included), and how many of those are pixels of the image
+    TileSlice tiles() const { return TileSlice{tile_first, tile_stride, (W + 7u) / 8u, W, H}; }
+    uint32_t tiles_owned() const {
+        const uint32_t n_tiles = ((W + 7u) / 8u) * ((H + 7u) / 8u);
+        return tile_first < n_tiles ? (n_tiles - tile_first + tile_stride - 1u) / tile_stride : 0u;
+    }
+    uint32_t npix_pass() const { return tile_stride == 1u ? npix : tiles_owned() * 64u; }
+    uint32_t pixels_owned() const {
+        if (tile_stride == 1u) return npix;
+        const uint32_t tx = (W + 7u) / 8u;
+        uint64_t n = 0;
+        for (uint32_t k = 0, t = tile_first; k < tiles_owned(); ++k, t += tile_stride) {
+            const uint32_t x0 = (t % tx) * 8u, y0 = (t / tx) * 8u;
+            n += uint64_t(std::min(8u, W - x0)) * std::min(8u, H - y0);
+        }
+        return uint32_t(n);
+    }
 };
 
 namespace rtint {
@@ -349,7 +368,8 @@ void refresh_camera(rt_ctx* c) {
 
 // One wavefront pass on lane `l`: `frames` samples of every pixel, bounce by bounce. Leaves radiance in l.rad.
 int run_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t frames, uint32_t frame_first, uint32_t frame_stride, uint32_t* seeds_out) {
-    const uint32_t n_slots = frames * c->npix;
+    const uint32_t npix = c->npix_pass();
+    const uint32_t n_slots = frames * npix;
     const bool count = (c->flags & RT_COUNT_TRAVERSAL) != 0;
     const PathDev state[2] = {l.state(0), l.state(1)};
     ShadowDev sq = l.sq();
@@ -358,8 +378,8 @@ int run_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t frames, uint32_t frame
     HIPCHK(c, hipMemsetAsync(l.counts.p, 0, Lane::counts_words() * 4, st));   // cursors and append counters
     {
         StageTimer tm(c, ST_RAYGEN, st);
-        hipLaunchKernelGGL(k_raygen, dim3(grid_for(c, n_slots, 8)), dim3(kBlock), 0, st, c->cam, state[0], rad, c->npix, n_slots,
-                           frame_first, frame_stride, seeds_out);
+        hipLaunchKernelGGL(k_raygen, dim3(grid_for(c, n_slots, 8)), dim3(kBlock), 0, st, c->cam, state[0], rad, npix, n_slots,
+                           frame_first, frame_stride, seeds_out, c->tiles());
     }
     const uint32_t trace_grid = trace_grid_for(c, n_slots, c->trace_blocks_per_cu);
     const uint32_t shade_grid = grid_for(c, n_slots, c->shade_blocks_per_cu);
@@ -826,6 +846,22 @@ extern "C" int rt_set_frame_slice(rt_ctx* c, uint32_t first, uint32_t stride) {
     return clear_accum(c);
 }
 
+extern "C" int rt_set_tile_slice(rt_ctx* c, uint32_t first, uint32_t stride) {
+    if (!c) return RT_ERR_INVALID;
+    if (stride == 0) return fail(c, RT_ERR_INVALID, "rt_set_tile_slice: stride is zero");
+    if (first >= stride) return fail(c, RT_ERR_INVALID, "rt_set_tile_slice: first must be below stride");
+    int rc;
+    if ((rc = bind_device(c)) != RT_OK) return rc;
+    const uint32_t old_first = c->tile_first, old_stride = c->tile_stride;
+    c->tile_first = first; c->tile_stride = stride;
+    if (c->npix_pass() > c->slot_cap) {          // an image of a few pixels, whose one overhanging tile outgrows the path buffers
+        c->tile_first = old_first; c->tile_stride = old_stride;
+        return fail(c, RT_ERR_UNSUPPORTED, "rt_set_tile_slice: the image is too small to be cut into tile slices");
+    }
+    forget_pass_cost(c);
+    return clear_accum(c);
+}
+
 extern "C" int rt_render(rt_ctx* c, uint32_t n_samples) {
     if (!c) return RT_ERR_INVALID;
     int rc;
@@ -861,14 +897,20 @@ extern "C" int rt_render(rt_ctx* c, uint32_t n_samples) {
     const bool cheap_paths = c->ns_per_slot > 0.0f && c->ns_per_slot < kCheapSlotNs;
     const bool always_alternate = !c->second_lane_for_short_passes || (cheap_paths && c->n_lanes > 1);
     const uint32_t min_passes = always_alternate ? std::min<uint32_t>(c->n_lanes, n_samples) : 1u;
-    uint32_t n_pass = std::max<uint32_t>((n_samples + c->fpp - 1) / c->fpp, min_passes);
+    if (c->npix_pass() > c->slot_cap) return fail(c, RT_ERR_UNSUPPORTED, "rt_render: the image is too small for the tile slice that is set");
+    // a tile slice has fewer pixels per frame than the path buffers were sized for: more frames fit a pass
+    uint32_t fpp = c->fpp;
+    if (c->tile_stride > 1u && !(c->flags & RT_REF_RGBA8_ACCUM))
+        fpp = std::max(1u, std::min(c->fpp_cfg ? c->fpp_cfg : 64u, c->slot_cap / std::max(1u, c->npix_pass())));
+    uint32_t n_pass = std::max<uint32_t>((n_samples + fpp - 1) / fpp, min_passes);
     const bool single_pass_call = n_pass == 1;
     uint32_t left = n_samples;
+    const uint32_t npix_pass = c->npix_pass(), pixels_owned = c->pixels_owned();
     while (left) {
         uint32_t frames = (left + n_pass - 1) / n_pass;
         --n_pass;
         uint32_t frame_first = c->slice_first + c->local_frame * c->slice_stride;
-        const bool alternate = always_alternate || uint64_t(frames) * c->npix <= kSmallPassSlots;
+        const bool alternate = always_alternate || uint64_t(frames) * npix_pass <= kSmallPassSlots;
         Lane& l = c->lanes[alternate ? c->next_lane : 0];
         if (alternate) c->next_lane = (c->next_lane + 1) % c->n_lanes;
         if (l.busy) HIPCHK(c, hipStreamWaitEvent(l.stream, l.consumed, 0));   // its previous radiance has been accumulated
@@ -880,16 +922,16 @@ extern "C" int rt_render(rt_ctx* c, uint32_t n_samples) {
         (void)hipGetLastError();
         if (time_it) HIPCHK(c, hipEventRecord(l.t_begin, l.stream));
         if ((rc = run_pass(c, l, l.stream, frames, frame_first, c->slice_stride, nullptr)) != RT_OK) return rc;
-        if (time_it) { HIPCHK(c, hipEventRecord(l.t_end, l.stream)); l.timed = true; l.timed_slots = uint64_t(frames) * c->npix; }
+        if (time_it) { HIPCHK(c, hipEventRecord(l.t_end, l.stream)); l.timed = true; l.timed_slots = uint64_t(frames) * npix_pass; }
         HIPCHK(c, hipEventRecord(l.pass_done, l.stream));
         HIPCHK(c, hipStreamWaitEvent(c->stream, l.pass_done, 0));
         {
             StageTimer tm(c, ST_ACCUM);
-            hipLaunchKernelGGL(k_accumulate, dim3(grid_for(c, c->npix, 8)), dim3(kBlock), 0, c->stream, l.rad.as<float4>(), c->sum.as<float4>(),
-                               c->accum8.as<uint32_t>(), c->fb.as<uint32_t>(), c->npix, frames, frame_first, c->slice_stride,
-                               (c->flags & RT_REF_RGBA8_ACCUM) ? 1u : 0u);
+            hipLaunchKernelGGL(k_accumulate, dim3(grid_for(c, npix_pass, 8)), dim3(kBlock), 0, c->stream, l.rad.as<float4>(), c->sum.as<float4>(),
+                               c->accum8.as<uint32_t>(), c->fb.as<uint32_t>(), npix_pass, frames, frame_first, c->slice_stride,
+                               (c->flags & RT_REF_RGBA8_ACCUM) ? 1u : 0u, c->tiles());
         }
-        if ((rc = finish_pass(c, l, c->stream, frames * c->npix)) != RT_OK) return rc;
+        if ((rc = finish_pass(c, l, c->stream, frames * pixels_owned)) != RT_OK) return rc;     // camera rays = pixels of the image
         HIPCHK(c, hipEventRecord(l.consumed, c->stream));
         l.busy = true;
         c->local_frame += frames;
@@ -1163,7 +1205,7 @@ extern "C" int rt_generate_rays(rt_ctx* c, uint32_t frame, float* origins, float
     int rc;
     if ((rc = bind_device(c)) != RT_OK) return rc;
     hipLaunchKernelGGL(k_raygen, dim3(grid_for(c, c->npix, 8)), dim3(kBlock), 0, c->stream, c->cam, c->lanes[0].state(0), c->lanes[0].rad.as<float4>(),
-                       c->npix, c->npix, frame, 1u, c->seeds.as<uint32_t>());
+                       c->npix, c->npix, frame, 1u, c->seeds.as<uint32_t>(), TileSlice{0u, 1u, (c->W + 7u) / 8u, c->W, c->H});
     HIPCHK(c, hipGetLastError());
     if ((rc = download_vec3(c, c->lanes[0].st_o[0].as<float4>(), c->npix, origins)) != RT_OK) return rc;
     if ((rc = download_vec3(c, c->lanes[0].st_d[0].as<float4>(), c->npix, directions)) != RT_OK) return rc;
@@ -1178,7 +1220,11 @@ extern "C" int rt_render_radiance(rt_ctx* c, uint32_t frame, float* rgb) {
     if ((rc = ready_to_render(c)) != RT_OK) return rc;
     if ((rc = bind_device(c)) != RT_OK) return rc;
     begin_call(c);
-    if ((rc = run_pass(c, c->lanes[0], c->stream, 1, frame, 1, nullptr)) != RT_OK) return rc;
+    const uint32_t tile_first = c->tile_first, tile_stride = c->tile_stride;      // this probe renders the whole frame
+    c->tile_first = 0; c->tile_stride = 1;
+    rc = run_pass(c, c->lanes[0], c->stream, 1, frame, 1, nullptr);
+    c->tile_first = tile_first; c->tile_stride = tile_stride;
+    if (rc != RT_OK) return rc;
     if ((rc = finish_pass(c, c->lanes[0], c->stream, c->npix)) != RT_OK) return rc;
     end_call(c);
     return download_vec3(c, c->lanes[0].rad.as<float4>(), c->npix, rgb);

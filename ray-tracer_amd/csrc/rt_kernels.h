@@ -718,15 +718,40 @@ RT_DEV void trace_persistent(const SceneDev& sc, const Work& work, uint32_t n, u
 
 // ---- kernels -------------------------------------------------------------------------------------------
 
-// Seed rule + thin-lens camera ray for every slot (main.comp:251; generate_ray.comp:2-29).
+// Which pixels a context renders. stride == 1: all of them, local pixel k = pixel k (row-major). stride > 1: the image is cut
+// into 8x8 tiles (the reference's workgroup footprint, main.comp:13), numbered row by row, and the context owns tiles first,
+// first + stride, ...; local pixel k is pixel (k & 7, (k >> 3) & 7) of its (k >> 6)-th tile. A tile that overhangs the right
+// or bottom edge has local pixels without a pixel: they get a ray that hits nothing and carries no throughput, and the
+// accumulation skips them.
+struct TileSlice {
+    uint32_t first, stride, tiles_x, width, height;
+    RT_DEV bool pixel_of(uint32_t local, uint32_t& px, uint32_t& py) const {
+        if (stride == 1u) { px = local % width; py = local / width; return true; }
+        const uint32_t tile = first + (local >> 6) * stride;
+        px = (tile % tiles_x) * 8u + (local & 7u);
+        py = (tile / tiles_x) * 8u + ((local >> 3) & 7u);
+        return px < width && py < height;
+    }
+};
+
+// Seed rule + thin-lens camera ray for every slot (main.comp:251; generate_ray.comp:2-29). `n_pixels` = local pixels per frame.
 __global__ __launch_bounds__(kBlock) void k_raygen(rt_camera cam, PathDev pd, float4* __restrict__ rad, uint32_t n_pixels, uint32_t n_slots,
-                                                   uint32_t frame_first, uint32_t frame_stride, uint32_t* seeds_out) {
+                                                   uint32_t frame_first, uint32_t frame_stride, uint32_t* seeds_out, TileSlice tiles) {
     const uint32_t W = cam.resolution[0];
     const float* m = cam.rotation;
     for (uint32_t slot = blockIdx.x * kBlock + threadIdx.x; slot < n_slots; slot += gridDim.x * kBlock) {
         uint32_t pixel = slot % n_pixels;
         uint32_t frame = frame_first + (slot / n_pixels) * frame_stride;
-        uint32_t px = pixel % W, py = pixel / W;
+        uint32_t px, py;
+        if (!tiles.pixel_of(pixel, px, py)) {
+            const float nan = __uint_as_float(0x7FC00000u);
+            pd.o[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            pd.d[slot] = make_float4(nan, nan, nan, 0.0f);                      // a non-finite ray reports a miss at once
+            pd.t[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(slot));
+            rad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (seeds_out) seeds_out[slot] = 0u;
+            continue;
+        }
         uint32_t seed = px + W * py + frame * py * px;
         float k = cam.focus_distance / cam.focal_length;
         float fpx = cam.view_port_uv[0] * k, fpy = cam.view_port_uv[1] * k;
@@ -1205,11 +1230,15 @@ RT_DEV uint32_t pack_rgba8(float r, float g, float b, float a) {
 // Folds the finished samples of one pass into the accumulator, in frame order (main.comp:260-267).
 // HDR mode: fp32 RGBA sum with the sample count in alpha; a non-finite sample component contributes 0.
 // Legacy mode: the shader's running mean stored in 8-bit UNORM every frame, plus the tone-mapped framebuffer.
+// `n_pixels` = local pixels per frame (the layout of `rad`); `tiles` maps a local pixel to its place in the image.
 __global__ __launch_bounds__(kBlock) void k_accumulate(const float4* __restrict__ rad, float4* __restrict__ sum, uint32_t* __restrict__ accum8,
                                                        uint32_t* __restrict__ framebuffer, uint32_t n_pixels,
                                                        uint32_t frames_in_pass, uint32_t frame_first, uint32_t frame_stride,
-                                                       uint32_t legacy8) {
-    for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < n_pixels; p += gridDim.x * kBlock) {
+                                                       uint32_t legacy8, TileSlice tiles) {
+    for (uint32_t lp = blockIdx.x * kBlock + threadIdx.x; lp < n_pixels; lp += gridDim.x * kBlock) {
+        uint32_t px, py;
+        if (!tiles.pixel_of(lp, px, py)) continue;
+        const uint32_t p = py * tiles.width + px;
         if (legacy8) {
             uint32_t w = accum8[p];
             float old[4] = {float(w & 255u) / 255.0f, float((w >> 8) & 255u) / 255.0f, float((w >> 16) & 255u) / 255.0f,
@@ -1217,7 +1246,7 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(const float4* __restrict_
             f3 fb = {0, 0, 0};
             float fa = 0.0f;
             for (uint32_t f = 0; f < frames_in_pass; ++f) {
-                float4 r = rad[size_t(f) * n_pixels + p];
+                float4 r = rad[size_t(f) * n_pixels + lp];
                 f3 c = suppress_fireflies(f3{r.x, r.y, r.z}, 5.0f);
                 float alpha = 1.0f / float(frame_first + f * frame_stride + 1u);
                 float nw[4] = {mixf(old[0], c.x, alpha), mixf(old[1], c.y, alpha), mixf(old[2], c.z, alpha), mixf(old[3], 1.0f, alpha)};
@@ -1232,7 +1261,7 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(const float4* __restrict_
         } else {
             float4 s = sum[p];
             for (uint32_t f = 0; f < frames_in_pass; ++f) {
-                float4 r = rad[size_t(f) * n_pixels + p];
+                float4 r = rad[size_t(f) * n_pixels + lp];
                 f3 c = suppress_fireflies(f3{r.x, r.y, r.z}, 5.0f);
                 s.x += isfinite(c.x) ? c.x : 0.0f;
                 s.y += isfinite(c.y) ? c.y : 0.0f;

@@ -16,6 +16,21 @@ def frame_slice(rank: int, world: int):
     return rank, world
 
 
+def tile_slice(rank: int, world: int):
+    """(first, stride) for rt_set_tile_slice: rank r renders the 8x8 tiles r, r + world, ... (numbered row by row)."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world of {world}")
+    return rank, world
+
+
+def tile_mask(width: int, height: int, first: int, stride: int) -> np.ndarray:
+    """Boolean (height, width) image of the pixels a tile slice owns."""
+    tx = (width + 7) // 8
+    yy, xx = np.mgrid[0:height, 0:width]
+    tile = (yy // 8) * tx + xx // 8
+    return (tile >= first) & ((tile - first) % stride == 0)
+
+
 def frames_of_rank(rank: int, world: int, n_local: int):
     first, stride = frame_slice(rank, world)
     return [first + k * stride for k in range(n_local)]

@@ -118,6 +118,10 @@ class HipRenderer:
     def set_frame_slice(self, first: int, stride: int):
         self._check(self.lib.rt_set_frame_slice(self._ctx, first, stride))
 
+    def set_tile_slice(self, first: int, stride: int):
+        """This renderer takes the 8x8 tiles first, first + stride, ... of every frame; the rest of its accumulator stays zero."""
+        self._check(self.lib.rt_set_tile_slice(self._ctx, first, stride))
+
     # dispatch_compute (renderer.rs:269-321): asynchronous
     def dispatch_compute(self, n_samples: int = 1):
         self._check(self.lib.rt_render(self._ctx, n_samples))

@@ -64,3 +64,23 @@ def test_frame_slice_validation():
     assert covered == list(range(20))
     m = mean_from_sum(np.array([[[2.0, 4.0, 6.0, 2.0]]], np.float32))
     assert m.tolist() == [[[1.0, 2.0, 3.0]]]
+
+
+@pytest.mark.parametrize("w,h", [(64, 32), (100, 52), (7, 9), (1, 1), (17, 8)])
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_tile_slices_partition_the_image(w, h, world):
+    """The 8x8 tiles dealt round-robin to the ranks cover every pixel exactly once, whatever the image size."""
+    from ray_tracer_amd.distributed import tile_mask, tile_slice
+    owners = np.zeros((h, w), np.int32)
+    for rank in range(world):
+        m = tile_mask(w, h, *tile_slice(rank, world))
+        assert m.shape == (h, w) and m.dtype == bool
+        owners += m
+        # whole tiles: every 8x8 block is owned entirely or not at all
+        for y0 in range(0, h, 8):
+            for x0 in range(0, w, 8):
+                blk = m[y0:y0 + 8, x0:x0 + 8]
+                assert blk.all() or not blk.any()
+    assert (owners == 1).all()
+    with pytest.raises(ValueError):
+        tile_slice(world, world)

@@ -106,7 +106,8 @@ def test_two_ranks_of_the_product_renderer_reduce_to_the_single_context_image(rt
     np.testing.assert_allclose(reduced, ref, rtol=2e-6, atol=1e-6)
 
 
-def test_bench_line_from_two_ranks_on_one_gpu():
+@pytest.mark.parametrize("partition,label,scaling,rays_per_pixel_step", [("samples", "sample-slice x2", "weak", 2), ("tiles", "tile-slice x2", "strong", 1)])
+def test_bench_line_from_two_ranks_on_one_gpu(partition, label, scaling, rays_per_pixel_step):
     """bench.py as the driver launches it for N = 2 (torch.distributed.run, one rank per process), with both ranks on GPU 0
     and the collectives over gloo (RT_BENCH_REHEARSE_ONE_GPU): rank 0 alone prints one JSON line, it carries the contract's
     keys, counts the samples of both ranks and says that it is a rehearsal."""
@@ -120,7 +121,7 @@ def test_bench_line_from_two_ranks_on_one_gpu():
     steps, warmup = 4, 2
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), str(root / "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup", str(warmup),
-           "--scale", "0.05", "--width", "320", "--height", "180"]
+           "--scale", "0.05", "--width", "320", "--height", "180", "--partition", partition]
     done = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
     assert done.returncode == 0, done.stderr[-2000:]
     lines = [l for l in done.stdout.splitlines() if l.strip()]
@@ -129,10 +130,13 @@ def test_bench_line_from_two_ranks_on_one_gpu():
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data", "config"):
         assert key in d, key
-    assert d["n_gpus"] == 2 and d["steps"] == steps and d["warmup"] == warmup and d["scaling"] == "weak"
+    assert d["n_gpus"] == 2 and d["steps"] == steps and d["warmup"] == warmup and d["scaling"] == scaling
     assert d["higher_is_better"] is True and d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "f32"
-    assert d["config"]["parallelism"] == "sample-slice x2" and "rehearsal" in d
+    assert d["config"]["parallelism"] == label and "rehearsal" in d
     assert d["value"] > 0 and d["ms_per_step"] > 0
-    # both ranks' samples are in the aggregate: at least two camera rays per pixel and step
-    assert d["extend_rays"] >= 2 * steps * 320 * 180
+    # both ranks' work is in the aggregate: two camera rays per pixel and step when the ranks take different frames, one
+    # when they share the frames tile by tile
+    assert d["extend_rays"] >= rays_per_pixel_step * steps * 320 * 180
+    if partition == "tiles":
+        assert d["extend_rays"] < 2 * steps * 320 * 180 * 4
     assert "cpu_baseline" not in d and "one_eighth_measured" not in d          # single-GPU legs stay out of an N > 1 line

@@ -815,3 +815,89 @@ def test_full_size_closest_hit_vs_oracle_sample(rt, oracle, full_atrium):
     h, _ = o.trace_closest(ro[pick], rd[pick])
     assert np.array_equal(g["prim"], h["prim"]) and np.array_equal(g["t"], h["t"])
     r.destroy()
+
+
+@pytest.mark.parametrize("w,h,world", [(160, 96, 2), (100, 52, 3), (37, 21, 4), (9, 7, 2)])
+@pytest.mark.parametrize("exact", [False, True])
+def test_tile_slices_sum_to_the_whole_image_bit_for_bit(rt, scene_cache, w, h, world, exact):
+    """The other multi-GPU partition: every context renders its 8x8 tiles of every frame, so each pixel is rendered by one
+    context with the seeds and in the order of a single-context run; the accumulators add up to that run's EXACTLY (no
+    summation-order tolerance), image sizes that are not multiples of the tile included."""
+    from ray_tracer_amd.distributed import tile_mask, tile_slice
+    sc = scene_cache("atrium", scale=0.05, spatial=True, width=w, height=h)
+    flags = rt.api.RT_EXACT_ORDER if exact else 0
+    whole = rt.HipRenderer.create(sc, max_bounces=5, flags=flags)
+    whole.render(5)
+    whole.render(2)
+    ref = whole.read_sum()
+    ref_counters = whole.counters()
+    whole.destroy()
+    total = np.zeros_like(ref)
+    rays = 0
+    for rank in range(world):
+        r = rt.HipRenderer.create(sc, max_bounces=5, flags=flags)
+        r.set_tile_slice(*tile_slice(rank, world))
+        r.render(5)
+        r.render(2)
+        part = r.read_sum()
+        mask = tile_mask(w, h, rank, world)
+        assert (part[~mask] == 0).all()                          # nothing outside its tiles, sample count included
+        assert (part[mask][:, 3] == 7).all() and r.sample_count() == 7
+        assert np.array_equal(part[mask], ref[mask])
+        total += part
+        c = r.counters()
+        assert c["camera_rays"] == 7 * int(mask.sum())
+        rays += c["extend_rays"]
+        r.destroy()
+    assert np.array_equal(total, ref)
+    assert rays == ref_counters["extend_rays"]
+
+
+def test_tile_slice_rules(rt, scene_cache):
+    sc = scene_cache("cornell", width=64, height=64)
+    r = rt.HipRenderer.create(sc, max_bounces=3)
+    lib = r.lib
+    assert lib.rt_set_tile_slice(r._ctx, 0, 0) == -1             # stride 0
+    assert lib.rt_set_tile_slice(r._ctx, 2, 2) == -1             # first must be below stride
+    r.render(3)
+    r.set_tile_slice(1, 2)                                        # restarts accumulation like the frame slice does
+    assert r.sample_count() == 0 and (r.read_sum() == 0).all()
+    r.render(2)
+    a = r.read_sum()
+    # resizing keeps the slice; the new image is cut into tiles afresh
+    r.handle_resize(40, 24)
+    r.render(1)
+    from ray_tracer_amd.distributed import tile_mask
+    b = r.read_sum()
+    m = tile_mask(40, 24, 1, 2)
+    assert (b[~m] == 0).all() and (b[m][:, 3] == 1).all()
+    # back to the whole image
+    r.set_tile_slice(0, 1)
+    r.render(1)
+    assert (r.read_sum()[..., 3] == 1).all()
+    # a tile slice and a frame slice together: tiles of every second frame
+    r.set_tile_slice(0, 2)
+    r.set_frame_slice(1, 2)
+    r.render(2)
+    c = r.read_sum()
+    m0 = tile_mask(40, 24, 0, 2)
+    assert (c[m0][:, 3] == 2).all() and (c[~m0] == 0).all()
+    assert a.shape == (64, 64, 4)
+    r.destroy()
+
+
+def test_full_size_tile_slices_sum_to_the_whole_bit_for_bit(rt, full_atrium):
+    """Two contexts rendering the even and the odd 8x8 tiles of frames 0..2 at 1920x1080 add up to one context rendering
+    the whole frames, exactly: the tile partition of the multi-GPU job, rehearsed on one GPU."""
+    whole = rt.HipRenderer.create(full_atrium, max_bounces=8)
+    whole.render(3)
+    ref = whole.read_sum()
+    whole.destroy()
+    total = np.zeros_like(ref)
+    for rank in range(2):
+        r = rt.HipRenderer.create(full_atrium, max_bounces=8)
+        r.set_tile_slice(rank, 2)
+        r.render(3)
+        total += r.read_sum()
+        r.destroy()
+    assert np.array_equal(total, ref)
