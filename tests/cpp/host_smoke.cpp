@@ -43,6 +43,14 @@ int main() {
         r.frame_complete();
         r.read_accum(again);
         if (rep.records_moved[0] != 0 || again != img) { std::puts("tuning changed the picture"); return 1; }
+        // the two tile slices of the image: each leaves the other's pixels alone, together they are the picture above
+        std::vector<float> half0(32 * 32 * 4), half1(32 * 32 * 4);
+        r.set_tile_slice(0, 2); r.dispatch_compute(2); r.frame_complete(); r.read_accum(half0);
+        r.set_tile_slice(1, 2); r.dispatch_compute(2); r.frame_complete(); r.read_accum(half1);
+        r.set_tile_slice(0, 1);
+        for (size_t k = 0; k < img.size(); ++k) {
+            if ((half0[k] != 0.0f && half1[k] != 0.0f) || half0[k] + half1[k] != img[k]) { std::puts("tile slices do not add up to the picture"); return 1; }
+        }
         std::puts("gpu render ok");
     } catch (const rt::Error& e) {
         if (e.code != RT_ERR_DEVICE) { std::printf("unexpected failure: %s\n", e.what()); return 1; }
