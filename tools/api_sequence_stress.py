@@ -1,5 +1,5 @@
 """Random sequences of entry points without synchronisation in between (render, poll, camera moves, resets, resizes, scene
-reloads, resident-set tuning, counter and image reads), on the GPU box. After every sequence the accumulated image must equal
+reloads, tile and frame slices, resident-set tuning, counter and image reads), on the GPU box. After every sequence the accumulated image must equal
 what a fresh context produces for the final scene, camera, resolution and sample count: any ordering mistake between the
 main stream, the lanes and their side streams shows up as a differing bit. usage: api_sequence_stress.py [rounds]"""
 import os, sys, time, dataclasses
@@ -20,9 +20,10 @@ for it in range(rounds):
     cam = sc.camera.copy()
     w, h = 160, 90
     samples = 0
+    tiles, frames = (0, 1), (0, 1)
     log = []
     for step in range(int(rng.integers(3, 14))):
-        op = rng.choice(["render", "render", "render", "poll", "camera", "reset", "resize", "reload", "tune", "read", "counters"])
+        op = rng.choice(["render", "render", "render", "poll", "camera", "reset", "resize", "reload", "tune", "read", "counters", "tiles", "frames"])
         log.append(op)
         if op == "render":
             n = int(rng.choice([1, 1, 2, 3, 7, 20])); r.dispatch_compute(n); samples += n
@@ -36,6 +37,10 @@ for it in range(rounds):
             w, h = int(rng.choice([96, 160, 200])), int(rng.choice([54, 90, 120])); r.handle_resize(w, h); samples = 0
         elif op == "reload":
             sc = pool[rng.integers(0, len(pool))]; r.upload_scene(sc); cam = sc.camera.copy(); samples = 0
+        elif op == "tiles":
+            st = int(rng.integers(1, 5)); tiles = (int(rng.integers(0, st)), st); r.set_tile_slice(*tiles); samples = 0
+        elif op == "frames":
+            st = int(rng.integers(1, 4)); frames = (int(rng.integers(0, 5)), st); r.set_frame_slice(*frames); samples = 0
         elif op == "tune":
             r.tune_resident_set()
         elif op == "read":
@@ -47,6 +52,8 @@ for it in range(rounds):
     r.destroy()
     ref = rt.HipRenderer.create(sc, max_bounces=5, flags=api.RT_SINGLE_STREAM, width=w, height=h)
     ref.set_camera(cam)
+    ref.set_tile_slice(*tiles)
+    ref.set_frame_slice(*frames)
     if samples:
         ref.render(samples)
     want = ref.read_sum()
