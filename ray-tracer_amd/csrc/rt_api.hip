@@ -376,6 +376,7 @@ int run_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t frames, uint32_t frame
     float4* hit = l.hit.as<float4>();
     float4* rad = l.rad.as<float4>();
     HIPCHK(c, hipMemsetAsync(l.counts.p, 0, Lane::counts_words() * 4, st));   // cursors and append counters
+    if (n_slots == 0) return RT_OK;                // a tile slice that owns no tile of a small image: nothing to trace
     {
         StageTimer tm(c, ST_RAYGEN, st);
         hipLaunchKernelGGL(k_raygen, dim3(grid_for(c, n_slots, 8)), dim3(kBlock), 0, st, c->cam, state[0], rad, npix, n_slots,
@@ -927,9 +928,11 @@ extern "C" int rt_render(rt_ctx* c, uint32_t n_samples) {
         HIPCHK(c, hipStreamWaitEvent(c->stream, l.pass_done, 0));
         {
             StageTimer tm(c, ST_ACCUM);
-            hipLaunchKernelGGL(k_accumulate, dim3(grid_for(c, npix_pass, 8)), dim3(kBlock), 0, c->stream, l.rad.as<float4>(), c->sum.as<float4>(),
-                               c->accum8.as<uint32_t>(), c->fb.as<uint32_t>(), npix_pass, frames, frame_first, c->slice_stride,
-                               (c->flags & RT_REF_RGBA8_ACCUM) ? 1u : 0u, c->tiles());
+            if (npix_pass != 0) {
+                hipLaunchKernelGGL(k_accumulate, dim3(grid_for(c, npix_pass, 8)), dim3(kBlock), 0, c->stream, l.rad.as<float4>(), c->sum.as<float4>(),
+                                   c->accum8.as<uint32_t>(), c->fb.as<uint32_t>(), npix_pass, frames, frame_first, c->slice_stride,
+                                   (c->flags & RT_REF_RGBA8_ACCUM) ? 1u : 0u, c->tiles());
+            }
         }
         if ((rc = finish_pass(c, l, c->stream, frames * pixels_owned)) != RT_OK) return rc;     // camera rays = pixels of the image
         HIPCHK(c, hipEventRecord(l.consumed, c->stream));

@@ -817,7 +817,7 @@ def test_full_size_closest_hit_vs_oracle_sample(rt, oracle, full_atrium):
     r.destroy()
 
 
-@pytest.mark.parametrize("w,h,world", [(160, 96, 2), (100, 52, 3), (37, 21, 4), (9, 7, 2)])
+@pytest.mark.parametrize("w,h,world", [(160, 96, 2), (100, 52, 3), (37, 21, 4), (9, 7, 2), (5, 3, 2)])      # the last: one tile, the second slice owns nothing
 @pytest.mark.parametrize("exact", [False, True])
 def test_tile_slices_sum_to_the_whole_image_bit_for_bit(rt, scene_cache, w, h, world, exact):
     """The other multi-GPU partition: every context renders its 8x8 tiles of every frame, so each pixel is rendered by one
