@@ -189,8 +189,8 @@ struct RegionMap {
 //   * the records of the largest nodes are read from a copy in LDS.
 // Occlusion queries (any hit below a fixed distance) do not depend on visiting order and walk a 4-wide tree instead.
 //
-// The traversal stack keeps its top entry in a register, the next kStackLds - 1 per lane in LDS (entry-major, so lanes
-// never conflict on a bank) and the rest, up to the reference's bound of 65, in per-lane scratch.
+// The traversal stack keeps its first kStackLds - 1 entries per lane in LDS (entry-major, so lanes never conflict on a
+// bank) and the rest, up to the reference's bound of 65, in per-lane scratch.
 
 constexpr uint32_t kDone = 0x7FFFFFFEu;       // lane has no node to visit; also the "empty" marker of the stack
 
@@ -199,8 +199,7 @@ struct LaneRay {
     float t, u, v;
     uint32_t prim;
     uint32_t cur;        // node record index, leaf reference, or kDone (lanes without a ray always hold kDone)
-    uint32_t tos;        // top of the stack (kDone = stack empty)
-    uint32_t sp;         // entries below the top; entry k (1-based) lives in memory slot k, slot 0 always reads kDone
+    uint32_t sp;         // entries on the stack; entry k (1-based) lives in memory slot k, slot 0 always reads kDone
     uint32_t item;       // handle of the work item this lane is tracing (what Work::load returned)
 };
 
@@ -217,17 +216,16 @@ RT_DEV uint32_t slot_load(const lds_u32* stack, const uint32_t* spill, uint32_t 
     if (__builtin_expect(slot < kStackLds, 1)) return stack[slot * kTraceBlock];
     return spill[slot - kStackLds];
 }
-// push: the old top moves to memory (an empty top rewrites slot 0 with the kDone it already holds)
+// push / pop. The whole stack lives in memory (an earlier version kept the top entry in a register, which takes the LDS
+// round trip out of a pop but costs every push three more vector-ALU instructions; the kernels are bound by
+// vector-ALU issue, and the plain form is 1-2 % faster). Popping the empty stack reads slot 0, i.e. kDone.
 RT_DEV void stack_push(lds_u32* stack, uint32_t* spill, LaneRay& r, uint32_t ref, bool lds_only) {
-    r.sp += r.tos != kDone ? 1u : 0u;
-    if (lds_only) stack[r.sp * kTraceBlock] = r.tos;
-    else slot_store(stack, spill, r.sp, r.tos);
-    r.tos = ref;
+    r.sp += 1u;
+    if (lds_only) stack[r.sp * kTraceBlock] = ref;
+    else slot_store(stack, spill, r.sp, ref);
 }
-// pop: returns the top; the entry below becomes the top
 RT_DEV uint32_t stack_pop(const lds_u32* stack, const uint32_t* spill, LaneRay& r, bool lds_only) {
-    uint32_t top = r.tos;
-    r.tos = lds_only ? uint32_t(stack[r.sp * kTraceBlock]) : slot_load(stack, spill, r.sp);
+    const uint32_t top = lds_only ? uint32_t(stack[r.sp * kTraceBlock]) : slot_load(stack, spill, r.sp);
     r.sp -= r.sp != 0u ? 1u : 0u;
     return top;
 }
@@ -574,7 +572,7 @@ RT_DEV void leaf_phase(const SceneDev& sc, LaneRay& r, unsigned long long parked
     }
     if (parked) {
         // ANYHIT: the caller only asks whether anything lies nearer than the initial distance, so a hit ends the ray
-        if (ANYHIT && r.prim != kNoPrim) { r.cur = kDone; r.tos = kDone; r.sp = 0; }
+        if (ANYHIT && r.prim != kNoPrim) { r.cur = kDone; r.sp = 0; }
         else r.cur = stack_pop(stack, spill, r, false);
     }
 }
@@ -600,9 +598,9 @@ RT_DEV void trace_persistent(const SceneDev& sc, const Work& work, uint32_t n, u
     constexpr uint32_t kLeafBatch = RT_LEAF_BATCH;   // intersect parked leaves once this many lanes wait on one
     static_assert(TREE != kTreeWide || ANYHIT, "the uncompressed 4-wide tree serves order-independent queries only");
     constexpr bool WIDE = TREE != kTreeBinary;
-    uint32_t spill[(WIDE ? kStackMaxWide : kStackMax) - kStackLds];
+    uint32_t spill[(WIDE ? kStackMaxWide : kStackMax) - kStackLds + 1];     // + 1: without a top-of-stack register the deepest entry takes a slot too
     LaneRay r;
-    r.cur = kDone; r.tos = kDone; r.sp = 0; r.item = 0; r.prim = kNoPrim; r.t = INFINITY; r.u = r.v = 0.0f;
+    r.cur = kDone; r.sp = 0; r.item = 0; r.prim = kNoPrim; r.t = INFINITY; r.u = r.v = 0.0f;
     stack[0] = kDone;                                // slot 0 of this lane's stack: what a pop of the empty stack reads
     r.o = r.d = r.inv = f3{0.0f, 0.0f, 0.0f};
     bool live = false;
@@ -648,7 +646,7 @@ RT_DEV void trace_persistent(const SceneDev& sc, const Work& work, uint32_t n, u
                 r.item = work.load(mine, r.o, r.d, tmax);
                 r.inv = f3{1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z};
                 r.t = tmax; r.u = 0.0f; r.v = 0.0f; r.prim = kNoPrim;
-                r.sp = 0; r.tos = kDone;
+                r.sp = 0;
                 { const uint32_t root = WIDE ? sc.wide_root : sc.root_ref; r.cur = root == kRefNone ? kDone : root; }
                 if (TREE == kTreeCw) {
                     // The compressed boxes are evaluated as fma(byte, s * inv, (p - o) * inv): an infinite reciprocal (a
@@ -705,7 +703,7 @@ RT_DEV void trace_persistent(const SceneDev& sc, const Work& work, uint32_t n, u
                     float t, u, v;
                     if (triangle_test(sc, r.o, r.d, first + k, t, u, v) && t < r.t) { r.t = t; r.u = u; r.v = v; r.prim = first + k; break; }
                 }
-                if (r.prim != kNoPrim) { r.cur = kDone; r.tos = kDone; r.sp = 0; }
+                if (r.prim != kNoPrim) { r.cur = kDone; r.sp = 0; }
                 else r.cur = stack_pop(stack, spill, r, false);
             }
         }
