@@ -901,3 +901,23 @@ def test_full_size_tile_slices_sum_to_the_whole_bit_for_bit(rt, full_atrium):
         total += r.read_sum()
         r.destroy()
     assert np.array_equal(total, ref)
+
+
+def test_tile_slices_in_the_legacy_8_bit_accumulator(rt, scene_cache):
+    """RT_REF_RGBA8_ACCUM (the shader's running mean in 8-bit UNORM, one frame per pass) under a tile slice: the owned pixels
+    hold exactly what the whole-image context holds there, the others stay zero, framebuffer included."""
+    from ray_tracer_amd.distributed import tile_mask
+    sc = scene_cache("cornell", width=52, height=36)
+    whole = rt.HipRenderer.create(sc, max_bounces=4, flags=rt.api.RT_REF_RGBA8_ACCUM)
+    whole.render(5)
+    ref, ref_fb = whole.read_accum(), whole.read_framebuffer()
+    whole.destroy()
+    for rank in range(3):
+        r = rt.HipRenderer.create(sc, max_bounces=4, flags=rt.api.RT_REF_RGBA8_ACCUM)
+        r.set_tile_slice(rank, 3)
+        r.render(5)
+        got, fb = r.read_accum(), r.read_framebuffer()
+        m = tile_mask(52, 36, rank, 3)
+        assert np.array_equal(got[m], ref[m]) and (got[~m] == 0).all()
+        assert np.array_equal(fb[m], ref_fb[m]) and (fb[~m] == 0).all()
+        r.destroy()
