@@ -860,9 +860,13 @@ inline uint8_t unorm8(float x) {
     return uint8_t(floorf(x * 255.0f + 0.5f));
 }
 
+// Worker threads when the caller does not say: the machine's, but at most 16 (a GPU box gives a job 16 cores of a much
+// larger host, and hardware_concurrency reports the whole host).
+inline uint32_t default_threads() { return std::min(16u, std::max(1u, std::thread::hardware_concurrency())); }
+
 template <class Fn>
 void parallel_rows(uint32_t rows, uint32_t threads, Fn fn) {
-    if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
+    if (threads == 0) threads = default_threads();
     std::atomic<uint32_t> next{0};
     auto body = [&](uint32_t tid) {
         for (;;) {
@@ -953,7 +957,7 @@ void orc_trace_closest(const void* s, uint32_t n, const float* o, const float* d
     struct H4 { float t, u, v; uint32_t prim; };
     H4* out = static_cast<H4*>(hits_out);
     uint32_t rows = (n + 1023) / 1024;
-    std::vector<Counters> local(std::max(1u, threads ? threads : std::thread::hardware_concurrency()));
+    std::vector<Counters> local(threads ? threads : default_threads());
     parallel_rows(rows, uint32_t(local.size()), [&](uint32_t r, uint32_t tid) {
         for (uint32_t i = r * 1024; i < std::min(n, (r + 1) * 1024); ++i) {
             Ray ray{v3(o + 3 * size_t(i)), v3(d + 3 * size_t(i))};
@@ -1026,7 +1030,7 @@ void orc_render_radiance(const void* s, const rt_camera* cam, uint32_t frame, ui
                          float* rgb, orc_counters* cnt, uint32_t threads) {
     const Scene& sc = *static_cast<const Scene*>(s);
     uint32_t W = cam->resolution[0], H = cam->resolution[1];
-    uint32_t nt = threads ? threads : std::max(1u, std::thread::hardware_concurrency());
+    uint32_t nt = threads ? threads : default_threads();
     std::vector<Counters> local(nt);
     parallel_rows(H, nt, [&](uint32_t y, uint32_t tid) {
         for (uint32_t x = 0; x < W; ++x) {
@@ -1053,7 +1057,7 @@ void orc_path_states(const void* s, const rt_camera* cam, uint32_t frame, uint32
                      rt_shade_vertex* out, uint8_t* reached, uint32_t threads) {
     const Scene& sc = *static_cast<const Scene*>(s);
     uint32_t W = cam->resolution[0], H = cam->resolution[1];
-    uint32_t nt = threads ? threads : std::max(1u, std::thread::hardware_concurrency());
+    uint32_t nt = threads ? threads : default_threads();
     parallel_rows(H, nt, [&](uint32_t y, uint32_t) {
         for (uint32_t x = 0; x < W; ++x) {
             uint32_t seed = pixel_seed(*cam, x, y, frame);
@@ -1124,7 +1128,7 @@ void orc_render(const void* s, const rt_camera* cam, uint32_t first, uint32_t st
                 uint32_t flags, float* sum_rgba, uint8_t* accum8, orc_counters* cnt, uint32_t threads) {
     const Scene& sc = *static_cast<const Scene*>(s);
     uint32_t W = cam->resolution[0], H = cam->resolution[1];
-    uint32_t nt = threads ? threads : std::max(1u, std::thread::hardware_concurrency());
+    uint32_t nt = threads ? threads : default_threads();
     std::vector<Counters> local(nt);
     for (uint32_t k = 0; k < n_frames; ++k) {
         uint32_t frame = first + k * stride;

@@ -431,4 +431,36 @@ def interior(width=3840, height=2160, scale=1.0, tex_size=1024) -> Scene:
                  name="interior-1.57M" if scale >= 1.0 else f"interior-{mesh.count()}")
 
 
-GENERATORS = {"cornell": cornell, "atrium": atrium, "glass_blob": glass_blob, "car": car, "interior": interior}
+# ------------------------------------------------------------------------------------------- analytic lights
+def lit_room(width=96, height=64, n_point=3) -> Scene:
+    """A small closed room lit by `n_point` analytic point lights (src/types/light.rs:25-32, type 0) AND two emissive ceiling
+    panels (8 triangles), so the light selector (disney.comp:669-695) crosses from the analytic buckets into the mesh bucket.
+    No shipped scene of the reference fills `lights`; this is the scene that exercises that branch of DirectLight."""
+    rng = _rng(6)
+    mesh = Mesh()
+    mats = default_material(8)
+    mats["base_colour"][:, :3] = rng.uniform(0.3, 0.85, size=(8, 3))
+    mats["roughness"] = rng.uniform(0.15, 1.0, size=8)
+    mats["metallic"][3] = 1.0
+    mats["clearcoat"][4] = 1.0
+    mats["spec_trans"][5] = 1.0                     # one glass box: shadow rays take the closest-hit (glass rule) variant
+    mats["roughness"][5] = 0.05
+    mats["base_colour"][7, :3] = 0.0
+    mats["emission"][7, :3] = (9.0, 8.0, 6.0)
+    X, Y, Z = 3.0, 2.5, 3.0
+    mesh.box([-X, 0.0, -Z], [X, Y, Z], 0)            # the room itself (outward winding; paths see its inside, two-sided BSDF)
+    for k in range(5):
+        c = np.array([-2.0 + k * 1.0, 0.35 + 0.1 * k, -0.8 + 0.45 * k])
+        mesh.box(c - 0.3, c + 0.3, 1 + k)
+    for xc in (-1.2, 1.2):                          # ceiling panels facing down, 4 triangles each
+        mesh.quad([[xc - 0.4, Y - 0.02, -0.4], [xc + 0.4, Y - 0.02, -0.4], [xc + 0.4, Y - 0.02, 0.4], [xc - 0.4, Y - 0.02, 0.4]], 7, split4=True)
+    lights = np.zeros(n_point, dtype=api.LIGHT)
+    for k in range(n_point):
+        lights["position"][k, :3] = (-1.8 + 1.8 * k, 1.4 + 0.3 * k, 1.6 - 0.9 * k)
+        lights["emission"][k, :3] = rng.uniform(6.0, 18.0, size=3)
+        lights["type"][k] = 0
+    cam = look_at_camera(width, height, (0.0, 1.3, 2.8), (0.0, 0.9, 0.0), focal_length=1.0, focus_distance=1.0)
+    return Scene(triangles=mesh.triangles(), materials=mats, camera=cam, lights=lights, name=f"lit-room-{n_point}pt")
+
+
+GENERATORS = {"cornell": cornell, "atrium": atrium, "glass_blob": glass_blob, "car": car, "interior": interior, "lit_room": lit_room}

@@ -83,6 +83,39 @@ def test_converged_pair_on_a_scene_whose_paths_do_decorrelate(rt, oracle, scene_
     r.destroy()
 
 
+# Converged pairs for the other three configurations, at a size the oracle affords (reduced triangle counts, same structure,
+# same materials, textures and sky; 192x108, 256 spp, 8 bounces). (scene, generator arguments, RMSE bar, mean-bias bar):
+# both relative to the image's mean radiance, about 4x the figures measured on an MI355X (in the comments), which the test prints.
+CONVERGED = [
+    ("atrium", {"scale": 0.08}, 1.5e-3, 1.0e-4),       # measured 2.8e-4 / 3e-7 (mean 0.294): open roof + white sky + 16 lamp triangles
+    ("car", {"scale": 0.05}, 1.0e-2, 1.0e-4),          # 2.3e-3 / 9e-6 (mean 0.253): clearcoat / metal / glass, base-colour atlas, sRGB cube-map sky, no lights
+    ("interior", {"scale": 0.02}, 5.0e-2, 1.0e-3),     # 1.5e-2 / 1.1e-4 (mean 0.150): closed room, 37 textures (all four bindings), glass rule for shadow rays
+    ("lit_room", {}, 2.0e-2, 2.0e-4),                  # 4.1e-3 / 2e-5 (mean 0.051): analytic point lights + emissive panels
+]
+
+
+@pytest.mark.parametrize("name,kw,rmse_bar,bias_bar", CONVERGED)
+def test_converged_pairs_of_the_other_configurations(rt, oracle, scene_cache, name, kw, rmse_bar, bias_bar):
+    sc = scene_cache(name, spatial=True, width=192, height=108, **kw)
+    r = rt.HipRenderer.create(sc, max_bounces=8)
+    o = oracle.OracleScene(sc)
+    spp = 256
+    r.render(spp)
+    gm = r.read_accum()[..., :3]
+    want, _, _ = o.render(spp, 8)
+    wm = want[..., :3] / want[..., 3:4]
+    assert np.isfinite(gm).all() and np.isfinite(wm).all()
+    rmse = float(np.sqrt(np.mean((gm - wm) ** 2)))
+    mean = float(wm.mean())
+    bias = abs(float(gm.mean()) - mean) / mean
+    same = rel_close(gm, wm, 1e-3, 1e-4).all(axis=-1).mean()
+    print(f"{sc.name} 192x108 {spp} spp: RMSE vs oracle {rmse:.2e} (mean radiance {mean:.4f}, relative {rmse / mean:.2e}), "
+          f"mean differs by {bias:.2e}, {same:.4f} of pixels equal to 1e-3")
+    assert rmse < rmse_bar * max(mean, 1e-3), (rmse, mean)          # bars are relative to the mean radiance of the image
+    assert bias < bias_bar
+    r.destroy()
+
+
 FULL = [("glass_blob", {}, 8), ("glass_blob", {}, 24), ("car", {}, 8), ("interior", {}, 8)]
 
 

@@ -540,6 +540,9 @@ def test_bsdf_eval_and_sample_within_1e5(pair, oracle, transmissive):
     plain_p = rel_close(gps[fin], ops[fin], 1e-5, 0.0).mean()
     plain_f = rel_close(gfs[fin], ofs[fin], 1e-5, 0.0).all(axis=1).mean()
     print(f"sampled BSDF ({'transmissive' if transmissive else 'opaque'}): {fin.sum()} finite of {n}; within plain 1e-5: pdf {plain_p:.4f}, f {plain_f:.4f}")
+    # floors for the plain-1e-5 shares (measured 0.9965 / 0.9957 opaque, 0.9956 / 0.9948 transmissive on random materials with
+    # roughness down to 0.001): a regression of ordinary inputs cannot hide inside the conditioning allowance
+    assert plain_p >= (0.993 if transmissive else 0.994) and plain_f >= (0.992 if transmissive else 0.993), (plain_p, plain_f)
     assert okL.all(), f"L: {(~okL).sum()} outside 1e-5 + conditioning"
     assert okp.all(), f"pdf: {(~okp).sum()} outside 1e-5 + conditioning"
     assert okf.all(), f"f: {(~okf).sum()} outside 1e-5 + conditioning"
@@ -556,7 +559,8 @@ def test_texture_and_cubemap_fetch_bit_exact(pair):
 
 # ------------------------------------------------------------------ whole path (a8-a14), accumulate (a16), display (a17)
 @pytest.mark.parametrize("name,kw,bounces", [(SCENES[0][0], SCENES[0][1], 4), (SCENES[1][0], SCENES[1][1], 8), (SCENES[2][0], SCENES[2][1], 8),
-                                              (SCENES[3][0], SCENES[3][1], 8), (SCENES[4][0], SCENES[4][1], 8)])
+                                              (SCENES[3][0], SCENES[3][1], 8), (SCENES[4][0], SCENES[4][1], 8),
+                                              ("lit_room", {}, 8)])         # analytic point lights beside emissive triangles
 def test_radiance_per_pixel_vs_oracle(pair, name, kw, bounces):
     r, o, _ = pair(name, kw, bounces=bounces)
     worst = 1.0

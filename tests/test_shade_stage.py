@@ -25,9 +25,16 @@ CASES = [
     ("car", {"scale": 0.03, "width": 96, "height": 54}),
     ("interior", {"scale": 0.01, "width": 96, "height": 54}),
     ("big_tables", {}),
+    ("lit_room", {}),            # analytic point lights + emissive triangles: both branches of the light selector
 ]
 MAX_BOUNCES = 8
 RTOL = 1e-5
+# Share of the sampled vertices whose BSDF pdf / throughput agree with the oracle to PLAIN 1e-5 relative (no conditioning
+# allowance), per scene: floors a little below the lowest share measured over bounces 0, 1 and 4 on an MI355X. The per-vertex
+# allowance below explains every vertex outside plain 1e-5; these floors keep a regression of ordinary vertices from hiding
+# inside it. The glass blob is the low one: a GGX lobe at roughness 0.001 turns one ulp of cos(phi) into percents of D.
+PLAIN_FLOOR = {"cornell": (0.995, 0.998), "atrium": (0.996, 0.998), "glass_blob": (0.93, 0.998), "car": (0.996, 0.997),
+               "interior": (0.985, 0.997), "big_tables": (0.995, 0.997), "lit_room": (0.997, 0.996)}
 
 
 @pytest.fixture(scope="module")
@@ -145,6 +152,9 @@ def test_shade_vertices_match_oracle(staged, oracle, name, kw, bounce):
     assert thr_ok[sampled].all(), f"throughput: {(~thr_ok[sampled]).sum()} of {sampled.sum()} outside 1e-5 + conditioning"
     pdf_plain = rel_close(g["pdf"], h["pdf"], RTOL, 0.0)[sampled].mean()
     thr_plain = rel_close(g["throughput"], h["throughput"], RTOL, 0.0).all(axis=1)[sampled].mean()
+    slack = 2.0 / max(1, sampled.sum())              # small samples (late bounces): two vertices of leeway
+    assert pdf_plain >= PLAIN_FLOOR[name][0] - slack, f"only {pdf_plain:.4f} of sampled pdfs within plain 1e-5"
+    assert thr_plain >= PLAIN_FLOOR[name][1] - slack, f"only {thr_plain:.4f} of sampled throughputs within plain 1e-5"
 
     # ---- next ray (where both continue)
     both = (g["alive"] == 1) & (h["alive"] == 1)
@@ -173,6 +183,48 @@ def test_shade_vertices_match_oracle(staged, oracle, name, kw, bounce):
     print(f"{name} bounce {bounce}: {n} vertices, {hitm.sum()} hits, {both.sum()} continue, {sh.sum()} light samples, "
           f"{alive_bad.sum()} audited flips, {sh_bad.sum()} underflow flips, "
           f"within plain 1e-5: pdf {pdf_plain:.4f}, throughput {thr_plain:.4f} of {sampled.sum()} sampled vertices")
+
+
+@pytest.mark.parametrize("bounce", [0, 2])
+def test_point_light_branch_of_direct_light(staged, bounce):
+    """SamplePointLight + the delta-light rule of DirectLight (disney.comp:216-225, 667-683, 706-713): a vertex whose light
+    index falls below the analytic-light count samples that light with pdf = numOfLights / dist^2 and weight 1 (no MIS);
+    indices from there on go to the emissive triangles. Checked field by field against the oracle AND against the closed
+    form evaluated here from the scene's own light records."""
+    r, o, sc = staged("lit_room", {})
+    n_point, n_mesh = len(sc.lights), len(sc.emissive_tris)
+    assert n_point == 3 and n_mesh == 8
+    v, reached = o.path_states(2, MAX_BOUNCES, bounce)
+    v = v[reached & (v["hit"]["prim"] != 0xFFFFFFFF)]
+    g = r.shade_vertices(bounce, v)
+    h = o.shade_vertices(bounce, v)
+    assert np.array_equal(g["light_index"], h["light_index"]) and np.array_equal(g["light_tri"], h["light_tri"])
+    point = g["light_index"] < n_point
+    assert 0.15 < point.mean() < 0.45 and g["light_index"].max() == n_point + n_mesh - 1       # 3 of 11 buckets
+    assert (g["light_tri"][point] == -1).all() and (g["light_tri"][~point] >= 0).all()
+    # no CDF / triangle draws for an analytic light: the RNG advanced by 1 (light) + 2 (BSDF) [+ 1 roulette] draws only
+    same_alive = g["alive"] == h["alive"]
+    assert np.array_equal(g["seed"][same_alive], h["seed"][same_alive])
+    sh = point & (g["has_shadow"] == 1) & (h["has_shadow"] == 1)
+    assert sh.sum() > 200
+    assert np.array_equal(g["shadow_o"][sh], h["shadow_o"][sh]) and np.array_equal(g["shadow_d"][sh], h["shadow_d"][sh])
+    assert np.array_equal(g["shadow_tmax"][sh], h["shadow_tmax"][sh]) and np.array_equal(g["light_pdf"][sh], h["light_pdf"][sh])
+    # closed form: direction = normalize(P - origin), tmax = |P - origin| - 0.001, pdf = numOfLights / dist^2
+    P = sc.lights["position"][g["light_index"][sh], :3].astype(np.float64)
+    to = P - g["shadow_o"][sh]
+    dist = np.linalg.norm(to, axis=1)
+    assert np.allclose(g["shadow_d"][sh], to / dist[:, None], rtol=0, atol=2e-6)
+    assert np.allclose(g["shadow_tmax"][sh], dist - 1e-3, rtol=2e-6)
+    assert np.allclose(g["light_pdf"][sh], (n_point + n_mesh) / dist ** 2, rtol=2e-6)
+    # weight 1: contribution = f * Le / pdf * throughput with f = DisneyEval for the light direction (1e-5, no conditioning
+    # allowance: V and L are exact on both sides)
+    assert close(g["bsdf_pdf_light"][sh], h["bsdf_pdf_light"][sh], 1e-9).all()
+    assert close(g["shadow_contrib"][sh], h["shadow_contrib"][sh], 1e-9 + 1e-6 * np.abs(h["shadow_contrib"][sh]).max(axis=1, keepdims=True)).all()
+    # and it is NOT what a MIS-weighted sample would have contributed: undo the weight 1 and compare
+    lp, bp = g["light_pdf"][sh].astype(np.float64), g["bsdf_pdf_light"][sh].astype(np.float64)
+    mis = lp * lp / (lp * lp + bp * bp)
+    assert (mis < 0.999).mean() > 0.5               # MIS would have scaled most of these samples down measurably
+    print(f"lit_room bounce {bounce}: {len(v)} hit vertices, {point.sum()} analytic-light picks, {sh.sum()} of them queued a shadow ray")
 
 
 def test_last_bounce_draws_no_bsdf_sample(staged):
