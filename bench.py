@@ -60,6 +60,20 @@ def algorithmic_bytes_connect(rays, node_pops, tri_tests, wide):
     return rays * (32 + 16 + 4 + 32) + node_pops * (112 if wide else 64) + tri_tests * 48
 
 
+def launch_ranks(n):
+    """`bench.py --gpus N` started by hand (no RANK in the environment): run the same command line as N ranks under
+    torch.distributed.run on 127.0.0.1 and return the launcher's exit code. Called before anything touches the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {n} without a launcher: starting {n} ranks through torch.distributed.run (port {port})", file=sys.stderr, flush=True)
+    return subprocess.run(cmd).returncode
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -86,8 +100,11 @@ def main():
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     elif n_gpus > 1:
-        print("bench.py: --gpus > 1 needs torch.distributed.run (one rank per GPU)", file=sys.stderr)
-        sys.exit(2)
+        # Started without a launcher: start one rank per GPU ourselves. This process has made no GPU call yet (argument
+        # parsing only), and it never makes one: the ranks are fresh child processes of torch.distributed.run, this
+        # process forwards their output (rank 0's JSON line) and leaves with the launcher's exit code.
+        os.dup2(real_stdout, 1)
+        sys.exit(launch_ranks(n_gpus))
 
     import ray_tracer_amd as rt
     from ray_tracer_amd import api, scenes
@@ -247,6 +264,12 @@ def main():
         "mpaths_per_sec": frames_total * npix / elapsed / 1e6,
         "scene_build_s": t_scene, "bvh_build_ms": scene.bvh_stats.get("build_ms"), "bvh_build_bench": bvh_bench,
     }
+    if dist is not None:
+        # what the collective layer itself saw: backend "nccl" is RCCL on ROCm
+        result["collective"] = {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "launched_as": "torch.distributed.run, one rank per GPU",
+                                "partition": args.partition}
+        if world != n_gpus:
+            result["collective"]["warning"] = f"--gpus {n_gpus} but the launcher started {world} ranks"
     if rehearse and world > 1:
         result["rehearsal"] = f"{world} ranks sharing GPU 0, collectives over gloo: exercises the N > 1 code path, not a measurement"
 

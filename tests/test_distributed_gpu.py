@@ -106,11 +106,13 @@ def test_two_ranks_of_the_product_renderer_reduce_to_the_single_context_image(rt
     np.testing.assert_allclose(reduced, ref, rtol=2e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("launcher", ["torch.distributed.run", "none"])
 @pytest.mark.parametrize("partition,label,scaling,rays_per_pixel_step", [("samples", "sample-slice x2", "weak", 2), ("tiles", "tile-slice x2", "strong", 1)])
-def test_bench_line_from_two_ranks_on_one_gpu(partition, label, scaling, rays_per_pixel_step):
+def test_bench_line_from_two_ranks_on_one_gpu(partition, label, scaling, rays_per_pixel_step, launcher):
     """bench.py as the driver launches it for N = 2 (torch.distributed.run, one rank per process), with both ranks on GPU 0
     and the collectives over gloo (RT_BENCH_REHEARSE_ONE_GPU): rank 0 alone prints one JSON line, it carries the contract's
-    keys, counts the samples of both ranks and says that it is a rehearsal."""
+    keys, counts the samples of both ranks and says that it is a rehearsal. launcher "none": plain `python bench.py --gpus 2`,
+    which has to start its two ranks by itself and print the same single line."""
     import json
     import subprocess
     import sys
@@ -119,9 +121,10 @@ def test_bench_line_from_two_ranks_on_one_gpu(partition, label, scaling, rays_pe
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["RT_BENCH_REHEARSE_ONE_GPU"] = "1"
     steps, warmup = 4, 2
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), str(root / "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup", str(warmup),
-           "--scale", "0.05", "--width", "320", "--height", "180", "--partition", partition]
+    head = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+            "--master-port", str(_free_port())] if launcher != "none" else [sys.executable]
+    cmd = head + [str(root / "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup", str(warmup),
+                  "--scale", "0.05", "--width", "320", "--height", "180", "--partition", partition]
     done = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
     assert done.returncode == 0, done.stderr[-2000:]
     lines = [l for l in done.stdout.splitlines() if l.strip()]
@@ -133,6 +136,7 @@ def test_bench_line_from_two_ranks_on_one_gpu(partition, label, scaling, rays_pe
     assert d["n_gpus"] == 2 and d["steps"] == steps and d["warmup"] == warmup and d["scaling"] == scaling
     assert d["higher_is_better"] is True and d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "f32"
     assert d["config"]["parallelism"] == label and "rehearsal" in d
+    assert d["collective"]["ranks"] == 2 and d["collective"]["partition"] == partition
     assert d["value"] > 0 and d["ms_per_step"] > 0
     # both ranks' work is in the aggregate: two camera rays per pixel and step when the ranks take different frames, one
     # when they share the frames tile by tile
