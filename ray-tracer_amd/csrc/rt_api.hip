@@ -487,7 +487,6 @@ extern "C" int rt_create(const rt_config* cfg, rt_ctx** out) {
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) c->n_cu = std::max(1, prop.multiProcessorCount);
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return bail(RT_ERR_DEVICE); }
     // Two lanes, the second one for short passes only: a pass of more than kSmallPassSlots paths keeps the machine busy
     // on its own, and a second concurrent pass only evicts the first one's tree from L2 / Infinity Cache (4583 vs 4446
     // Mrays/s at 32-frame passes), but short passes (an interactive host renders one sample per call) spend most of
@@ -516,6 +515,12 @@ extern "C" int rt_create(const rt_config* cfg, rt_ctx** out) {
             c->n_cu = v;
             masked = true;
         }
+    }
+    // Every stream of a confined context carries the mask, the main stream (accumulate, clears, copies) included: a process
+    // whose context launched on masked and on ordinary streams side by side did not return from the HIP runtime's exit
+    // handler, one whose streams are all masked does.
+    if ((masked ? hipExtStreamCreateWithCUMask(&c->stream, 8, cu_mask) : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+        c->err = "hipStreamCreate failed"; return bail(RT_ERR_DEVICE);
     }
     for (uint32_t i = 0; i < c->n_lanes; ++i) {
         Lane& l = c->lanes[i];
