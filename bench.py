@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--no-eighth", action="store_true", help="skip the measured 32-CU (one eighth of the chip) leg")
     ap.add_argument("--eighth-child", action="store_true", help=argparse.SUPPRESS)   # internal: run only the 32-CU leg
     ap.add_argument("--exact-order", action="store_true", help="RT_EXACT_ORDER: the reference's tree and visiting order (bit-exact ids) instead of the default compressed 4-wide tree")
+    ap.add_argument("--exact-arith", action="store_true", help="RT_EXACT_ARITH: shade stage with correctly rounded division / square root and no FMA (implied by --exact-order)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--frames-per-pass", type=int, default=0)
     ap.add_argument("--partition", choices=("samples", "tiles"), default="samples",
@@ -114,7 +115,7 @@ def main():
             print(f"[bench +{time.time() - t_start:.1f}s] {msg}", file=sys.stderr, flush=True)
     t_start = time.time()
 
-    base_flags = api.RT_EXACT_ORDER if args.exact_order else 0
+    base_flags = (api.RT_EXACT_ORDER if args.exact_order else 0) | (api.RT_EXACT_ARITH if args.exact_arith else 0)
     gen = scenes.GENERATORS[args.scene]
     kw = {"width": args.width, "height": args.height}
     if args.scene != "cornell":
@@ -372,7 +373,7 @@ def main():
         cmd = [sys.executable, os.path.abspath(__file__), "--eighth-child", "--steps", str(max(2, args.steps // 4)),
                "--warmup", str(max(1, args.warmup // 4)), "--width", str(args.width), "--height", str(args.height),
                "--bounces", str(args.bounces), "--scene", args.scene, "--scale", str(args.scale),
-               "--frames-per-pass", str(args.frames_per_pass), "--bvh", args.bvh] + (["--exact-order"] if args.exact_order else [])
+               "--frames-per-pass", str(args.frames_per_pass), "--bvh", args.bvh] + (["--exact-order"] if args.exact_order else []) + (["--exact-arith"] if args.exact_arith else [])
         try:
             env = {k_: v_ for k_, v_ in os.environ.items()
                    if k_ not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE")}

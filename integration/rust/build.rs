@@ -15,11 +15,11 @@ fn main() {
     let lib = out.join("librt_hip.so");
     let hipcc = env::var("HIPCC").unwrap_or_else(|_| "/opt/rocm/bin/hipcc".to_string());
 
-    let sources = ["rt_api.hip", "scene_pack.cpp", "bvh_build.cpp", "bvh_sbvh.cpp", "bvh_sweep.cpp"];
+    let sources = ["rt_api.hip", "rt_shade_fast.hip", "scene_pack.cpp", "bvh_build.cpp", "bvh_sbvh.cpp", "bvh_sweep.cpp"];
     for s in sources.iter() {
         println!("cargo:rerun-if-changed={}", csrc.join(s).display());
     }
-    for h in ["rt_kernels.h", "rt_device_math.h", "rt_internal.h", "bvh_common.h"].iter() {
+    for h in ["rt_kernels.h", "rt_kernels_common.h", "rt_shade.h", "rt_device_math.h", "rt_internal.h", "bvh_common.h"].iter() {
         println!("cargo:rerun-if-changed={}", csrc.join(h).display());
     }
     println!("cargo:rerun-if-changed={}", root.join("include").join("rt_api.h").display());

@@ -23,6 +23,7 @@ pub const RT_COUNT_TRAVERSAL: u32 = 1 << 3;
 pub const RT_KERNEL_TIMING: u32 = 1 << 4;
 pub const RT_SINGLE_STREAM: u32 = 1 << 5;
 pub const RT_EXACT_ORDER: u32 = 1 << 6;
+pub const RT_EXACT_ARITH: u32 = 1 << 7;
 
 pub const RT_NO_TEXTURE: u32 = 0xFFFF_FFFF;
 pub const RT_STATIC_MAX_RAYS: u32 = 1 << 18;

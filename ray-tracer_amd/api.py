@@ -55,6 +55,7 @@ RT_COUNT_TRAVERSAL = 1 << 3
 RT_KERNEL_TIMING = 1 << 4
 RT_SINGLE_STREAM = 1 << 5
 RT_EXACT_ORDER = 1 << 6
+RT_EXACT_ARITH = 1 << 7
 
 
 class RtConfig(C.Structure):

@@ -95,8 +95,10 @@ struct Lane {
     uint32_t* con_cursor() const { return counts.as<uint32_t>() + 3 * (kMaxBounces + 1); }
     uint32_t* aux_cursor() const { return counts.as<uint32_t>() + 4 * (kMaxBounces + 1); }   // stage-level entry points
     // per bounce: kQueueShards append counters for the next bounce's paths, then kQueueShards for the light samples
-    uint32_t* shard_counts(uint32_t bounce) const { return counts.as<uint32_t>() + 4 * (kMaxBounces + 1) + 4 + bounce * 2 * kQueueShards; }
-    static size_t counts_words() { return 4 * (kMaxBounces + 1) + 4 + size_t(kMaxBounces) * 2 * kQueueShards; }
+    uint32_t* shard_counts(uint32_t bounce) const { return counts.as<uint32_t>() + kCountersAt + size_t(bounce) * 2 * kQueueShards * kCounterStride; }
+    uint32_t* shadow_counts(uint32_t bounce) const { return shard_counts(bounce) + size_t(kQueueShards) * kCounterStride; }
+    static constexpr size_t kCountersAt = ((4 * (kMaxBounces + 1) + 4 + 63) / 64) * 64;     // the counters start on a 256-byte boundary
+    static size_t counts_words(uint32_t bounces = kMaxBounces) { return kCountersAt + size_t(bounces) * 2 * kQueueShards * kCounterStride; }
 };
 
 }  // namespace
@@ -140,6 +142,7 @@ struct rt_ctx {
     rt_camera cam{};
     bool have_scene = false, have_camera = false;
     bool fast_requested = true;               // the caller did not ask for RT_EXACT_ORDER
+    bool exact_arith = false;                 // shade stage in the exact arithmetic mode (RT_EXACT_ARITH, implied by RT_EXACT_ORDER)
     bool fast = true;                         // walk the compressed 4-wide tree (false: RT_EXACT_ORDER, or a scene the compressed tree cannot hold)
     bool camera_within_limit = true;          // the camera sits where the compressed tree's boxes are conservative (SceneDev::origin_limit)
     bool lanes_must_wait = true;              // something other than rt_render has used the main stream since the last pass was queued
@@ -375,7 +378,7 @@ int run_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t frames, uint32_t frame
     ShadowDev sq = l.sq();
     float4* hit = l.hit.as<float4>();
     float4* rad = l.rad.as<float4>();
-    HIPCHK(c, hipMemsetAsync(l.counts.p, 0, Lane::counts_words() * 4, st));   // cursors and append counters
+    HIPCHK(c, hipMemsetAsync(l.counts.p, 0, Lane::counts_words(c->max_bounces) * 4, st));   // cursors and the append counters of the bounces in use
     if (n_slots == 0) return RT_OK;                // a tile slice that owns no tile of a small image: nothing to trace
     {
         StageTimer tm(c, ST_RAYGEN, st);
@@ -402,8 +405,10 @@ int run_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t frames, uint32_t frame
         if (connect_pending) { HIPCHK(c, hipStreamWaitEvent(st, l.connected, 0)); connect_pending = false; }
         {
             StageTimer tm(c, ST_SHADE, st);
-            ShadeParams sp{b, c->max_bounces, c->flags, rin, hit, out, l.shard_counts(b), sq, l.shard_counts(b) + kQueueShards, c->shard_cap, rad, nullptr};
-            if (c->sd.n_mat <= kLdsMats && c->sd.n_emissive <= kLdsLights) hipLaunchKernelGGL((k_shade<true, false>), dim3(shade_grid), dim3(kBlock), 0, st, c->sd, in, sp);
+            ShadeParams sp{b, c->max_bounces, c->flags, rin, hit, out, l.shard_counts(b), sq, l.shadow_counts(b), c->shard_cap, rad, nullptr};
+            const bool lds_tables = c->sd.n_mat <= kLdsMats && c->sd.n_emissive <= kLdsLights;
+            if (!c->exact_arith) rtint::launch_shade_fast(lds_tables, false, shade_grid, st, c->sd, in, sp);
+            else if (lds_tables) hipLaunchKernelGGL((k_shade<true, false>), dim3(shade_grid), dim3(kBlock), 0, st, c->sd, in, sp);
             else hipLaunchKernelGGL((k_shade<false, false>), dim3(shade_grid), dim3(kBlock), 0, st, c->sd, in, sp);
         }
         if (c->sd.n_light + c->sd.n_emissive != 0) {
@@ -416,7 +421,7 @@ int run_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t frames, uint32_t frame
             {
                 StageTimer tm(c, ST_CONNECT, cs);
                 const bool any = c->sd.has_glass == 0;
-                const Regions rsh{l.shard_counts(b) + kQueueShards, c->shard_cap, 0u};
+                const Regions rsh{l.shadow_counts(b), c->shard_cap, 0u};
                 auto kern = c->fast ? (count ? (any ? k_connect<true, true, true> : k_connect<true, false, true>) : (any ? k_connect<false, true, true> : k_connect<false, false, true>))
                                     : (count ? (any ? k_connect<true, true, false> : k_connect<true, false, false>) : (any ? k_connect<false, true, false> : k_connect<false, false, false>));
                 hipLaunchKernelGGL(kern, dim3(trace_grid), dim3(kTraceBlock), 0, cs, c->sd, sq, rad, rsh, RT_CURSOR(l.con_cursor() + b), c->tstats());
@@ -478,6 +483,7 @@ extern "C" int rt_create(const rt_config* cfg, rt_ctx** out) {
     c->max_bounces = mb; c->flags = cfg->flags; c->fpp_cfg = cfg->frames_per_pass;
     c->fast_requested = (cfg->flags & RT_EXACT_ORDER) == 0;
     c->fast = c->fast_requested;
+    c->exact_arith = (cfg->flags & (RT_EXACT_ARITH | RT_EXACT_ORDER)) != 0;
     auto bail = [&](int code) { std::string m = c->err; rt_destroy(c); fail(nullptr, code, m); return code; };
     if (uint64_t(cfg->width) * cfg->height > 0x7FFFFFFFull) { c->err = "resolution too large"; return bail(RT_ERR_UNSUPPORTED); }
     int rc;
@@ -1275,9 +1281,11 @@ extern "C" int rt_shade_vertices(rt_ctx* c, uint32_t n, uint32_t bounce, const r
     for (DevBuf* b : {&l.rad, &l.st_o[1], &l.st_d[1], &l.st_t[1], &l.sq_o, &l.sq_d, &l.sq_c}) HIPCHK(c, hipMemsetAsync(b->p, 0, bytes, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));     // the host vectors above are pageable: do not let them go before the copies ran
     ShadeParams sp{bounce, c->max_bounces, c->flags, Regions{nullptr, c->shard_cap, n}, l.hit.as<float4>(), l.state(1), l.shard_counts(bounce),
-                   l.sq(), l.shard_counts(bounce) + kQueueShards, c->shard_cap, l.rad.as<float4>(), c->probe.as<uint4>()};
+                   l.sq(), l.shadow_counts(bounce), c->shard_cap, l.rad.as<float4>(), c->probe.as<uint4>()};
     const uint32_t grid = grid_for(c, n, c->shade_blocks_per_cu);
-    if (c->sd.n_mat <= kLdsMats && c->sd.n_emissive <= kLdsLights) hipLaunchKernelGGL((k_shade<true, true>), dim3(grid), dim3(kBlock), 0, c->stream, c->sd, l.state(0), sp);
+    const bool lds_tables = c->sd.n_mat <= kLdsMats && c->sd.n_emissive <= kLdsLights;
+    if (!c->exact_arith) rtint::launch_shade_fast(lds_tables, true, grid, c->stream, c->sd, l.state(0), sp);
+    else if (lds_tables) hipLaunchKernelGGL((k_shade<true, true>), dim3(grid), dim3(kBlock), 0, c->stream, c->sd, l.state(0), sp);
     else hipLaunchKernelGGL((k_shade<false, true>), dim3(grid), dim3(kBlock), 0, c->stream, c->sd, l.state(0), sp);
     HIPCHK(c, hipGetLastError());
     std::vector<float4> rad(n), so(n), sdir(n), scon(n);
@@ -1339,7 +1347,8 @@ static int bsdf_common(rt_ctx* c, uint32_t n, const rt_material* mats, const flo
     HIPCHK(c, put(of, nullptr, size_t(n) * 12));
     HIPCHK(c, put(op, nullptr, size_t(n) * 4));
     BsdfIo io{dm.as<float4>(), de.as<float>(), dv.as<float>(), dn.as<float>(), dl.as<float>(), dr.as<float>(), oL.as<float>(), of.as<float>(), op.as<float>()};
-    hipLaunchKernelGGL(k_bsdf, dim3((n + 63) / 64), dim3(64), 0, c->stream, io, n, r ? 1 : 0);
+    if (!c->exact_arith) rtint::launch_bsdf_fast((n + 63) / 64, 64, c->stream, io, n, r ? 1 : 0);
+    else hipLaunchKernelGGL(k_bsdf, dim3((n + 63) / 64), dim3(64), 0, c->stream, io, n, r ? 1 : 0);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (out_L) HIPCHK(c, hipMemcpy(out_L, oL.p, size_t(n) * 12, hipMemcpyDeviceToHost));

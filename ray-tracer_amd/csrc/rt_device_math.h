@@ -1,9 +1,16 @@
 // Device-side vector algebra, RNG, texture fetch and the Disney principled BSDF for the shade stage.
 //
-// Arithmetic conventions (chosen so a CPU evaluation of the reference shader can be compared value by
-// value): IEEE binary32 with no FMA contraction (the translation unit is built with -ffp-contract=off),
-// correctly rounded division and square root, min/max = fminf/fmaxf, mix(x,y,a) = x*(1-a) + y*a,
-// normalize(v) = v * (1/sqrt(v.v)), dot products summed left to right.
+// Two arithmetic modes, chosen per translation unit; every function below lives in an inline namespace named after the
+// mode, so the two sets of device functions and kernels never share a symbol.
+//   exact (default): chosen so a CPU evaluation of the reference shader can be compared value by value: IEEE binary32
+//     with no FMA contraction (the translation unit is built with -ffp-contract=off), correctly rounded division and
+//     square root, min/max = fminf/fmaxf, mix(x,y,a) = x*(1-a) + y*a, normalize(v) = v * (1/sqrt(v.v)), dot products
+//     summed left to right. Everything but sin/cos/log/exp/pow then equals the CPU evaluation bit for bit.
+//   fast (RT_FAST_ARITH, used by the shade stage unless the caller asks for exact arithmetic): the same formulas with
+//     the hardware's reciprocal, reciprocal square root and square root (1 ulp each) in place of the correctly rounded
+//     operations, FMA contraction, log/exp/pow through the hardware's base-2 instructions and a short-range sine/cosine.
+//     Each operation is within 1-2 ulp of the exact one; results stay within 1e-5 relative of the exact mode wherever the
+//     formula itself is well conditioned.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -11,10 +18,88 @@
 
 #define RT_DEV __device__ __forceinline__
 
+#ifdef RT_FAST_ARITH
+#define RT_ARITH_NS fast_arith
+#else
+#define RT_ARITH_NS exact_arith
+#endif
+
 namespace rtdev {
 
 struct f3 { float x, y, z; };
 struct f4 { float x, y, z, w; };
+
+// ---- material in registers (wire layout: six float4, src/types/material.rs:6-30)
+struct Mat {
+    f3 base; f3 emission;
+    float metallic, roughness, subsurface, specular_tint, sheen, sheen_tint, clearcoat, clearcoat_roughness, spec_trans, ior;
+    uint32_t base_tex, mr_tex, normal_tex, emission_tex;
+};
+
+// LDS-resident copies of small scene tables are read through explicit LDS pointer types (ds_read_b128 / ds_read_b32).
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4f lds_v4f;
+typedef __attribute__((address_space(3))) float lds_f32;
+
+// ---- textures: RGBA8 holding sRGB values, bilinear, one mip (image.rs:307-318, sampler.rs:10-34)
+struct TexView {
+    const uint32_t* __restrict__ texels;   // all 2-D images back to back, one packed RGBA8 word per texel
+    const uint4* __restrict__ table;       // per image {first texel, width, height, 0}
+    uint32_t n_tex;
+    const uint32_t* __restrict__ sky;      // 6 faces back to back
+    uint32_t sky_w, sky_h;
+    const float* __restrict__ srgb;        // 256-entry decode table
+};
+
+// Everything about a shading point that both the light-sampling evaluation and the BSDF sample need:
+// the frame around the face-forward normal, the view vector in it, and the two tint colours.
+struct ShadePoint {
+    f3 T, B, N;      // Onb(N) — disney.comp:191-196
+    f3 V;            // view vector, local
+    f3 spec_col, sheen_col;
+    float eta;
+};
+struct LobeWeights { float diffuse, refl, refr, coat; };
+
+inline namespace RT_ARITH_NS {
+
+#ifdef RT_FAST_ARITH
+RT_DEV float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+RT_DEV float fdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+RT_DEV float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+RT_DEV float frsq(float x) { return __builtin_amdgcn_rsqf(x); }
+RT_DEV float flog(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994531f; }          // v_log_f32 is log2
+RT_DEV float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+RT_DEV float fpow(float x, float y) { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }   // x >= 0
+// sin and cos of an angle in [0, 2 pi] (what every caller passes: 2 pi times a uniform number): the nearest multiple of
+// pi/2 is removed in two steps (the float nearest pi/2 minus its error), then degree-7 / degree-8 polynomials on [-pi/4, pi/4].
+RT_DEV void fsincos(float phi, float& s, float& c) {
+    const float q = rintf(phi * 0.636619772367581343f);
+    float t = __builtin_fmaf(q, -1.57079637050628662109375f, phi);
+    t = __builtin_fmaf(q, 4.37113882867379116e-8f, t);
+    const float t2 = t * t;
+    float sp = __builtin_fmaf(t2, -1.9515295891e-4f, 8.3321608736e-3f);
+    sp = __builtin_fmaf(sp, t2, -1.6666654611e-1f);
+    const float sn = __builtin_fmaf(sp * t2, t, t);
+    float cp = __builtin_fmaf(t2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    cp = __builtin_fmaf(cp, t2, 4.166664568298827e-2f);
+    const float cs = __builtin_fmaf(cp * t2, t2, __builtin_fmaf(t2, -0.5f, 1.0f));
+    const int k = int(q);
+    const bool swap = (k & 1) != 0;
+    const float sv = swap ? cs : sn, cv = swap ? sn : cs;
+    s = (k & 2) ? -sv : sv;
+    c = ((k + 1) & 2) ? -cv : cv;
+}
+#else
+RT_DEV float frcp(float x) { return 1.0f / x; }
+RT_DEV float fdiv(float a, float b) { return a / b; }
+RT_DEV float fsqrt(float x) { return sqrtf(x); }
+RT_DEV float frsq(float x) { return 1.0f / sqrtf(x); }
+RT_DEV float flog(float x) { return logf(x); }
+RT_DEV float fexp(float x) { return expf(x); }
+RT_DEV float fpow(float x, float y) { return powf(x, y); }
+RT_DEV void fsincos(float phi, float& s, float& c) { s = sinf(phi); c = cosf(phi); }
+#endif
 
 RT_DEV f3 mk3(float a) { return {a, a, a}; }
 RT_DEV f3 operator+(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
@@ -22,12 +107,16 @@ RT_DEV f3 operator-(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 RT_DEV f3 operator*(f3 a, f3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
 RT_DEV f3 operator*(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
 RT_DEV f3 operator*(float s, f3 a) { return {s * a.x, s * a.y, s * a.z}; }
+#ifdef RT_FAST_ARITH
+RT_DEV f3 operator/(f3 a, float s) { const float r = frcp(s); return {a.x * r, a.y * r, a.z * r}; }
+#else
 RT_DEV f3 operator/(f3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+#endif
 RT_DEV f3 operator-(f3 a) { return {-a.x, -a.y, -a.z}; }
 RT_DEV float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 RT_DEV f3 cross(f3 a, f3 b) { return {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y}; }
-RT_DEV float length(f3 a) { return sqrtf(dot(a, a)); }
-RT_DEV f3 normalize(f3 a) { float r = 1.0f / sqrtf(dot(a, a)); return a * r; }
+RT_DEV float length(f3 a) { return fsqrt(dot(a, a)); }
+RT_DEV f3 normalize(f3 a) { float r = frsq(dot(a, a)); return a * r; }
 RT_DEV float mixf(float x, float y, float a) { return x * (1.0f - a) + y * a; }
 RT_DEV f3 mix3(f3 x, f3 y, float a) { return x * (1.0f - a) + y * a; }
 RT_DEV float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
@@ -47,14 +136,8 @@ RT_DEV float pcg_next(uint32_t& s) {
 }
 
 RT_DEV float luminance(f3 c) { return 0.212671f * c.x + 0.715160f * c.y + 0.072169f * c.z; }  // disney.comp:30-33
-RT_DEV float power_heuristic(float a, float b) { float t = a * a; return t / (b * b + t); }    // disney.comp:185-189
+RT_DEV float power_heuristic(float a, float b) { float t = a * a; return fdiv(t, b * b + t); }    // disney.comp:185-189
 
-// ---- material in registers (wire layout: six float4, src/types/material.rs:6-30)
-struct Mat {
-    f3 base; f3 emission;
-    float metallic, roughness, subsurface, specular_tint, sheen, sheen_tint, clearcoat, clearcoat_roughness, spec_trans, ior;
-    uint32_t base_tex, mr_tex, normal_tex, emission_tex;
-};
 RT_DEV Mat unpack_material(float4 a, float4 b, float4 c, float4 d, float4 e, float4 f) {
     Mat m;
     m.base = {a.x, a.y, a.z};
@@ -71,21 +154,8 @@ RT_DEV Mat load_material(const float4* __restrict__ mats, uint32_t idx) {
     return unpack_material(p[0], p[1], p[2], p[3], p[4], p[5]);
 }
 
-// LDS-resident copies of small scene tables are read through explicit LDS pointer types (ds_read_b128 / ds_read_b32).
-typedef float v4f __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) v4f lds_v4f;
-typedef __attribute__((address_space(3))) float lds_f32;
 RT_DEV float4 lds_load4(const lds_v4f* p) { v4f v = *p; return make_float4(v.x, v.y, v.z, v.w); }
 
-// ---- textures: RGBA8 holding sRGB values, bilinear, one mip (image.rs:307-318, sampler.rs:10-34)
-struct TexView {
-    const uint32_t* __restrict__ texels;   // all 2-D images back to back, one packed RGBA8 word per texel
-    const uint4* __restrict__ table;       // per image {first texel, width, height, 0}
-    uint32_t n_tex;
-    const uint32_t* __restrict__ sky;      // 6 faces back to back
-    uint32_t sky_w, sky_h;
-    const float* __restrict__ srgb;        // 256-entry decode table
-};
 // `srgb_lds`, when not null, is a copy of the decode table in LDS: three dependent table reads per texel, twelve per
 // bilinear fetch, then stay off the vector-memory pipeline.
 RT_DEV f4 decode_texel(const TexView& tv, const lds_f32* srgb_lds, uint32_t w) {
@@ -123,7 +193,7 @@ RT_DEV f4 sample_cube(const TexView& tv, f3 d, const lds_f32* srgb_lds = nullptr
     if (az >= ax && az >= ay) { face = d.z < 0.0f ? 5 : 4; sc = d.z < 0.0f ? -d.x : d.x; tc = -d.y; ma = az; }
     else if (ay >= ax) { face = d.y < 0.0f ? 3 : 2; sc = d.x; tc = d.y < 0.0f ? -d.z : d.z; ma = ay; }
     else { face = d.x < 0.0f ? 1 : 0; sc = d.x < 0.0f ? d.z : -d.z; tc = -d.y; ma = ax; }
-    float s = 0.5f * sc / ma + 0.5f, t = 0.5f * tc / ma + 0.5f;
+    float s = fdiv(0.5f * sc, ma) + 0.5f, t = fdiv(0.5f * tc, ma) + 0.5f;
     if (!isfinite(s)) s = 0.5f;
     if (!isfinite(t)) t = 0.5f;
     int W = int(tv.sky_w), H = int(tv.sky_h);
@@ -143,17 +213,17 @@ RT_DEV float gtr1(float ndh, float a) {
     if (a >= 1.0f) return kInvPi;
     float a2 = a * a;
     float t = 1.0f + (a2 - 1.0f) * ndh * ndh;
-    return (a2 - 1.0f) / (kPi * logf(a2) * t);
+    return fdiv(a2 - 1.0f, kPi * flog(a2) * t);
 }
 RT_DEV float gtr2(float ndh, float a) {
     float a2 = a * a;
     float t = 1.0f + (a2 - 1.0f) * ndh * ndh;
-    return a2 / (kPi * t * t);
+    return fdiv(a2, kPi * t * t);
 }
 RT_DEV float smith_g(float ndv, float alpha) {
     float a = alpha * alpha;
     float b = ndv * ndv;
-    return (2.0f * ndv) / (ndv + sqrtf(a + b - a * b));
+    return fdiv(2.0f * ndv, ndv + fsqrt(a + b - a * b));
 }
 RT_DEV float schlick(float u) {
     float m = clampf(1.0f - u, 0.0f, 1.0f);
@@ -163,41 +233,46 @@ RT_DEV float schlick(float u) {
 RT_DEV float dielectric_fresnel(float cos_i, float eta) {
     float sin2_t = eta * eta * (1.0f - cos_i * cos_i);
     if (sin2_t > 1.0f) return 1.0f;
-    float cos_t = sqrtf(fmaxf(1.0f - sin2_t, 0.0f));
-    float rs = (eta * cos_t - cos_i) / (eta * cos_t + cos_i);
-    float rp = (eta * cos_i - cos_t) / (eta * cos_i + cos_t);
+    float cos_t = fsqrt(fmaxf(1.0f - sin2_t, 0.0f));
+    float rs = fdiv(eta * cos_t - cos_i, eta * cos_t + cos_i);
+    float rp = fdiv(eta * cos_i - cos_t, eta * cos_i + cos_t);
     return 0.5f * (rs * rs + rp * rp);
 }
 RT_DEV f3 sample_gtr1(float rgh, float r1) {
     float a = fmaxf(0.001f, rgh);
     float a2 = a * a;
     float phi = r1 * kTwoPi;
-    float ct = sqrtf((1.0f - powf(a2, 1.0f - r1)) / (1.0f - a2));
-    float st = clampf(sqrtf(1.0f - (ct * ct)), 0.0f, 1.0f);
-    float sp = sinf(phi), cp = cosf(phi);
+    float ct = fsqrt(fdiv(1.0f - fpow(a2, 1.0f - r1), 1.0f - a2));
+    float st = clampf(fsqrt(1.0f - (ct * ct)), 0.0f, 1.0f);
+    float sp, cp;
+    fsincos(phi, sp, cp);
     return {st * cp, st * sp, ct};
 }
 RT_DEV f3 sample_ggx_vndf(f3 V, float rgh, float r1, float r2) {
     f3 Vh = normalize(f3{rgh * V.x, rgh * V.y, V.z});
     float lensq = Vh.x * Vh.x + Vh.y * Vh.y;
-    f3 T1 = lensq > 0.0f ? f3{-Vh.y, Vh.x, 0.0f} * (1.0f / sqrtf(lensq)) : f3{1.0f, 0.0f, 0.0f};
+    f3 T1 = lensq > 0.0f ? f3{-Vh.y, Vh.x, 0.0f} * frsq(lensq) : f3{1.0f, 0.0f, 0.0f};
     f3 T2 = cross(Vh, T1);
-    float r = sqrtf(r1);
+    float r = fsqrt(r1);
     float phi = 2.0f * kPi * r2;
-    float t1 = r * cosf(phi);
-    float t2 = r * sinf(phi);
+    float sphi, cphi;
+    fsincos(phi, sphi, cphi);
+    float t1 = r * cphi;
+    float t2 = r * sphi;
     float s = 0.5f * (1.0f + Vh.z);
-    t2 = (1.0f - s) * sqrtf(1.0f - t1 * t1) + s * t2;
-    f3 Nh = t1 * T1 + t2 * T2 + sqrtf(fmaxf(0.0f, 1.0f - t1 * t1 - t2 * t2)) * Vh;
+    t2 = (1.0f - s) * fsqrt(1.0f - t1 * t1) + s * t2;
+    f3 Nh = t1 * T1 + t2 * T2 + fsqrt(fmaxf(0.0f, 1.0f - t1 * t1 - t2 * t2)) * Vh;
     return normalize(f3{rgh * Nh.x, rgh * Nh.y, fmaxf(0.0f, Nh.z)});
 }
 RT_DEV f3 cosine_hemisphere(float r1, float r2) {
-    float r = sqrtf(r1);
+    float r = fsqrt(r1);
     float phi = kTwoPi * r2;
+    float sphi, cphi;
+    fsincos(phi, sphi, cphi);
     f3 d;
-    d.x = r * cosf(phi);
-    d.y = r * sinf(phi);
-    d.z = sqrtf(fmaxf(0.0f, 1.0f - d.x * d.x - d.y * d.y));
+    d.x = r * cphi;
+    d.y = r * sphi;
+    d.z = fsqrt(fmaxf(0.0f, 1.0f - d.x * d.x - d.y * d.y));
     return d;
 }
 RT_DEV f3 reflect3(f3 I, f3 N) { return I - N * (2.0f * dot(N, I)); }
@@ -205,17 +280,9 @@ RT_DEV f3 refract3(f3 I, f3 N, float eta) {
     float d = dot(N, I);
     float k = 1.0f - eta * eta * (1.0f - d * d);
     if (k < 0.0f) return mk3(0.0f);
-    return I * eta - N * (eta * d + sqrtf(k));
+    return I * eta - N * (eta * d + fsqrt(k));
 }
 
-// Everything about a shading point that both the light-sampling evaluation and the BSDF sample need:
-// the frame around the face-forward normal, the view vector in it, and the two tint colours.
-struct ShadePoint {
-    f3 T, B, N;      // Onb(N) — disney.comp:191-196
-    f3 V;            // view vector, local
-    f3 spec_col, sheen_col;
-    float eta;
-};
 RT_DEV f3 to_local(const ShadePoint& sp, f3 v) { return {dot(v, sp.T), dot(v, sp.B), dot(v, sp.N)}; }
 RT_DEV f3 to_world(const ShadePoint& sp, f3 v) { return v.x * sp.T + v.y * sp.B + v.z * sp.N; }
 
@@ -229,7 +296,7 @@ RT_DEV ShadePoint make_shade_point(const Mat& m, float eta, f3 Vworld, f3 N) {
     sp.eta = eta;
     float lum = luminance(m.base);                                   // GetSpecColor, disney.comp:453-460
     f3 ctint = lum > 0.0f ? m.base / lum : mk3(1.0f);
-    float f0 = (1.0f - eta) / (1.0f + eta);
+    float f0 = fdiv(1.0f - eta, 1.0f + eta);
     sp.spec_col = mix3(f0 * f0 * mix3(mk3(1.0f), ctint, m.specular_tint), m.base, m.metallic);
     sp.sheen_col = mix3(mk3(1.0f), ctint, m.sheen_tint);
     return sp;
@@ -239,7 +306,6 @@ RT_DEV float fresnel_mix(const Mat& m, float eta, float vdh) {
     return mixf(dielectric_fresnel(vdh, eta), schlick(vdh), m.metallic);
 }
 
-struct LobeWeights { float diffuse, refl, refr, coat; };
 RT_DEV LobeWeights lobe_weights(const Mat& m, f3 spec_col, float fresnel) {  // disney.comp:462-474
     LobeWeights w;
     w.diffuse = luminance(m.base) * (1.0f - m.metallic) * (1.0f - m.spec_trans);
@@ -247,7 +313,12 @@ RT_DEV LobeWeights lobe_weights(const Mat& m, f3 spec_col, float fresnel) {  // 
     w.refr = (1.0f - fresnel) * (1.0f - m.metallic) * m.spec_trans * luminance(m.base);
     w.coat = m.clearcoat * (1.0f - m.metallic);
     float total = w.diffuse + w.refl + w.refr + w.coat;
+#ifdef RT_FAST_ARITH
+    const float inv_total = frcp(total);
+    w.diffuse *= inv_total; w.refl *= inv_total; w.refr *= inv_total; w.coat *= inv_total;
+#else
     w.diffuse /= total; w.refl /= total; w.refr /= total; w.coat /= total;
+#endif
     return w;
 }
 
@@ -261,7 +332,7 @@ RT_DEV f3 eval_diffuse(const Mat& m, f3 sheen_col, f3 V, f3 L, f3 H, float& pdf)
     float Fd = mixf(1.0f, Fd90, FL) * mixf(1.0f, Fd90, FV);
     float Fss90 = ldh * ldh * m.roughness;
     float Fss = mixf(1.0f, Fss90, FL) * mixf(1.0f, Fss90, FV);
-    float ss = 1.25f * (Fss * (1.0f / (L.z + V.z) - 0.5f) + 0.5f);
+    float ss = 1.25f * (Fss * (frcp(L.z + V.z) - 0.5f) + 0.5f);
     f3 Fsheen = FH * m.sheen * sheen_col;
     pdf = L.z * kInvPi;
     return (kInvPi * mixf(Fd, ss, m.subsurface) * m.base + Fsheen) * (1.0f - m.metallic) * (1.0f - m.spec_trans);
@@ -275,8 +346,8 @@ RT_DEV f3 eval_spec_reflection(const Mat& m, float eta, f3 spec_col, f3 V, f3 L,
     float G1 = smith_g(fabsf(V.z), m.roughness);
     float G2 = G1 * smith_g(fabsf(L.z), m.roughness);
     float vdh = dot(V, H);
-    float jac = 1.0f / (4.0f * vdh);
-    pdf = G1 * fmaxf(0.0f, vdh) * D * jac / V.z;
+    float jac = frcp(4.0f * vdh);
+    pdf = fdiv(G1 * fmaxf(0.0f, vdh) * D * jac, V.z);
     return F * D * G2 / (4.0f * L.z * V.z);
 }
 RT_DEV f3 eval_spec_refraction(const Mat& m, float eta, f3 V, f3 L, f3 H, float& pdf) {  // :416-434
@@ -289,9 +360,13 @@ RT_DEV f3 eval_spec_refraction(const Mat& m, float eta, f3 V, f3 L, f3 H, float&
     denom *= denom;
     float G1 = smith_g(fabsf(V.z), m.roughness);
     float G2 = G1 * smith_g(fabsf(L.z), m.roughness);
-    float jac = fabsf(ldh) / denom;
-    pdf = G1 * fmaxf(0.0f, vdh) * D * jac / V.z;
+    float jac = fdiv(fabsf(ldh), denom);
+    pdf = fdiv(G1 * fmaxf(0.0f, vdh) * D * jac, V.z);
+#ifdef RT_FAST_ARITH
+    f3 tint = {fsqrt(m.base.x), fsqrt(m.base.y), fsqrt(m.base.z)};
+#else
     f3 tint = {powf(m.base.x, 0.5f), powf(m.base.y, 0.5f), powf(m.base.z, 0.5f)};
+#endif
     return tint * (1.0f - m.metallic) * m.spec_trans * (1.0f - F) * D * G2 * fabsf(vdh) * fabsf(ldh) * eta * eta /
            (denom * fabsf(L.z) * fabsf(V.z));
 }
@@ -303,7 +378,7 @@ RT_DEV f3 eval_clearcoat(const Mat& m, f3 V, f3 L, f3 H, float& pdf) {  // :436-
     float F = mixf(0.04f, 1.0f, FH);
     float D = gtr1(H.z, m.clearcoat_roughness);
     float G = smith_g(L.z, m.clearcoat_roughness) * smith_g(V.z, m.clearcoat_roughness);
-    float jac = 1.0f / (4.0f * vdh);
+    float jac = frcp(4.0f * vdh);
     pdf = D * H.z * jac;
     return mk3(1.0f) * m.clearcoat * F * D * G / (4.0f * L.z * V.z);
 }
@@ -336,7 +411,7 @@ RT_DEV f3 disney_sample(const Mat& m, const ShadePoint& sp, float r1, float r2, 
     if (lobe_out) *lobe_out = r1 < c0 ? 0 : (r1 < c1 ? 1 : (r1 < c2 ? 2 : 3));
     f3 L;
     if (r1 < c0) {
-        r1 /= c0;
+        r1 = fdiv(r1, c0);
         L = cosine_hemisphere(r1, r2);
         f3 H = normalize(L + V);
         f = eval_diffuse(m, sp.sheen_col, V, L, H, out_pdf);
@@ -349,7 +424,7 @@ RT_DEV f3 disney_sample(const Mat& m, const ShadePoint& sp, float r1, float r2, 
         const int lobe = r1 < c1 ? 1 : (r1 < c2 ? 2 : 3);
         const float lo = lobe == 1 ? c0 : (lobe == 2 ? c1 : c2);
         const float hi = lobe == 1 ? c1 : (lobe == 2 ? c2 : 1.0f);
-        r1 = (r1 - lo) / (hi - lo);
+        r1 = fdiv(r1 - lo, hi - lo);
         f3 H;
         if (lobe != 3) H = sample_ggx_vndf(V, m.roughness, r1, r2);
         else H = sample_gtr1(m.clearcoat_roughness, r1);
@@ -364,4 +439,5 @@ RT_DEV f3 disney_sample(const Mat& m, const ShadePoint& sp, float r1, float r2, 
     return f * fabsf(dot(sp.N, Lworld));
 }
 
+}  // inline namespace
 }  // namespace rtdev

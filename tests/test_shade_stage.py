@@ -2,6 +2,9 @@
 DirectLight disney.comp:623-720; MeshLightPdf disney.comp:297-330; DisneySample disney.comp:476-558), on identical
 inputs, vertex by vertex, against the CPU oracle's statement of the same vertex.
 
+The renderer runs in the exact arithmetic mode (RT_EXACT_ARITH: correctly rounded division and square root, no FMA), the
+mode whose arithmetic equals the oracle's outside sin/cos/log/exp/pow; tests/test_fast_arith.py holds the default mode.
+
 Inputs are the oracle's own path states on arrival at vertex `bounce` (ray, closest hit, throughput, carried pdf, RNG
 state), so no upstream difference reaches the comparison. Bars:
   * RNG state, light index, emissive-table entry and lobe: exact (they depend on +,-,*,/ and sqrt only);
@@ -45,7 +48,7 @@ def staged(rt, oracle, scene_cache):
         key = (name, tuple(sorted(kw.items())))
         if key not in made:
             sc = big_tables_scene() if name == "big_tables" else scene_cache(name, **kw)
-            made[key] = (rt.HipRenderer.create(sc, max_bounces=MAX_BOUNCES), oracle.OracleScene(sc), sc)
+            made[key] = (rt.HipRenderer.create(sc, max_bounces=MAX_BOUNCES, flags=rt.api.RT_EXACT_ARITH), oracle.OracleScene(sc), sc)
         return made[key]
     yield get
     for r, _, _ in made.values():

@@ -3,7 +3,7 @@
 mkdir -p gpurun_out
 for lib in "$@"; do
   name=$(basename $lib .so)
-  RT_HIP_LIB=$PWD/$lib timeout -k 10 300 python -u bench.py --steps 64 --warmup 8 --no-cpu-baseline > gpurun_out/var_$name.json 2> gpurun_out/var_$name.err || { echo "$name failed"; tail -3 gpurun_out/var_$name.err; exit 1; }
+  RT_HIP_LIB=$PWD/$lib timeout -k 10 300 python -u bench.py --steps ${VB_STEPS:-20} --warmup ${VB_WARMUP:-5} --no-cpu-baseline --no-eighth > gpurun_out/var_$name.json 2> gpurun_out/var_$name.err || { echo "$name failed"; tail -3 gpurun_out/var_$name.err; exit 1; }
   python3 - <<PY
 import json
 d=json.load(open("gpurun_out/var_$name.json"))
