@@ -91,22 +91,24 @@ struct Lane {
     std::vector<DevBuf*> path_buffers() {
         return {&st_o[0], &st_o[1], &st_d[0], &st_d[1], &st_t[0], &st_t[1], &hit, &rad, &sq_o, &sq_d, &sq_c};
     }
-    uint32_t* ext_cursor() const { return counts.as<uint32_t>() + 2 * (kMaxBounces + 1); }   // one work cursor per bounce
-    uint32_t* con_cursor() const { return counts.as<uint32_t>() + 3 * (kMaxBounces + 1); }
-    uint32_t* aux_cursor() const { return counts.as<uint32_t>() + 4 * (kMaxBounces + 1); }   // stage-level entry points
+    // work cursors: a set of kTailCursors counters (kCursorSetWords words) per traversal launch of a pass, and one set for
+    // the stage-level entry points
+    uint32_t* aux_cursor() const { return counts.as<uint32_t>(); }
+    uint32_t* ext_cursor(uint32_t bounce) const { return counts.as<uint32_t>() + size_t(1 + bounce) * kCursorSetWords; }
+    uint32_t* con_cursor(uint32_t bounce) const { return counts.as<uint32_t>() + size_t(1 + kMaxBounces + 1 + bounce) * kCursorSetWords; }
     // per bounce: kQueueShards append counters for the next bounce's paths, then kQueueShards for the light samples
     uint32_t* shard_counts(uint32_t bounce) const { return counts.as<uint32_t>() + kCountersAt + size_t(bounce) * 2 * kQueueShards * kCounterStride; }
     uint32_t* shadow_counts(uint32_t bounce) const { return shard_counts(bounce) + size_t(kQueueShards) * kCounterStride; }
-    static constexpr size_t kCountersAt = ((4 * (kMaxBounces + 1) + 4 + 63) / 64) * 64;     // the counters start on a 256-byte boundary
+    static constexpr size_t kCountersAt = size_t(1 + 2 * (kMaxBounces + 1)) * kCursorSetWords;   // behind the cursor sets
     static size_t counts_words(uint32_t bounces = kMaxBounces) { return kCountersAt + size_t(bounces) * 2 * kQueueShards * kCounterStride; }
 };
 
 }  // namespace
 
-// Fixed staging area of rt_trace_closest_static: [work cursor, 256 B][origins 3 x f32][directions 3 x f32][hits 16 B].
+// Fixed staging area of rt_trace_closest_static: [work cursors, 2 KiB][origins 3 x f32][directions 3 x f32][hits 16 B].
 // Host code never uses the array's name as an address: each device holds its own copy, whose address
 // hipGetSymbolAddress reports once per device (static_scratch_for) and which is kept in g_static_scratch.
-constexpr size_t kStaticCursorBytes = 256;
+constexpr size_t kStaticCursorBytes = size_t(kCursorSetWords) * 4;
 constexpr size_t kStaticBytes = kStaticCursorBytes + size_t(RT_STATIC_MAX_RAYS) * (12 + 12 + 16);
 static __device__ __align__(256) unsigned char scratch[kStaticBytes];
 
@@ -399,7 +401,7 @@ int run_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t frames, uint32_t frame
             // camera rays may start anywhere; every later ray starts on a surface, inside the scene bounds
             const bool fast = c->fast && (b != 0 || c->camera_within_limit);
             auto kern = count ? (fast ? k_extend<true, true> : k_extend<true, false>) : (fast ? k_extend<false, true> : k_extend<false, false>);
-            hipLaunchKernelGGL(kern, dim3(trace_grid), dim3(kTraceBlock), 0, st, c->sd, in, hit, rin, RT_CURSOR(l.ext_cursor() + b), c->tstats());
+            hipLaunchKernelGGL(kern, dim3(trace_grid), dim3(kTraceBlock), 0, st, c->sd, in, hit, rin, RT_CURSOR(l.ext_cursor(b)), c->tstats());
         }
         // shade rewrites the light-sample queue and adds to the radiance slots the previous bounce's shadow rays still use
         if (connect_pending) { HIPCHK(c, hipStreamWaitEvent(st, l.connected, 0)); connect_pending = false; }
@@ -424,7 +426,7 @@ int run_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t frames, uint32_t frame
                 const Regions rsh{l.shadow_counts(b), c->shard_cap, 0u};
                 auto kern = c->fast ? (count ? (any ? k_connect<true, true, true> : k_connect<true, false, true>) : (any ? k_connect<false, true, true> : k_connect<false, false, true>))
                                     : (count ? (any ? k_connect<true, true, false> : k_connect<true, false, false>) : (any ? k_connect<false, true, false> : k_connect<false, false, false>));
-                hipLaunchKernelGGL(kern, dim3(trace_grid), dim3(kTraceBlock), 0, cs, c->sd, sq, rad, rsh, RT_CURSOR(l.con_cursor() + b), c->tstats());
+                hipLaunchKernelGGL(kern, dim3(trace_grid), dim3(kTraceBlock), 0, cs, c->sd, sq, rad, rsh, RT_CURSOR(l.con_cursor(b)), c->tstats());
             }
             if (overlap) { HIPCHK(c, hipEventRecord(l.connected, l.side)); connect_pending = true; }
         }
@@ -1102,7 +1104,7 @@ static int trace_common(rt_ctx* c, uint32_t n, const float* origins, const float
     HIPCHK(c, hits.ensure(size_t(n) * 16));
     const bool count = (c->flags & RT_COUNT_TRAVERSAL) != 0;
     begin_call(c);
-    HIPCHK(c, hipMemsetAsync(c->aux_cursor(), 0, 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->aux_cursor(), 0, kCursorSetWords * 4, c->stream));
     {
         StageTimer tm(c, shadow ? ST_CONNECT : ST_EXTEND);
         const bool fast = c->fast && origins_within_limit(c, n, origins);
@@ -1185,7 +1187,7 @@ extern "C" int rt_bench_trace(rt_ctx* c, uint32_t n, const float* origins, const
     const bool fast = c->fast && origins_within_limit(c, n, origins);
     auto kern = fast ? k_trace_rays<false, true> : k_trace_rays<false, false>;
     auto launch = [&] {
-        (void)hipMemsetAsync(c->aux_cursor(), 0, 4, c->stream);
+        (void)hipMemsetAsync(c->aux_cursor(), 0, kCursorSetWords * 4, c->stream);
         hipLaunchKernelGGL(kern, dim3(trace_grid_for(c, n, c->trace_blocks_per_cu)), dim3(kTraceBlock), 0, c->stream, c->sd, ro.as<float4>(), rd.as<float4>(), n, shadow, hits.as<float4>(), RT_CURSOR(c->aux_cursor()), c->tstats());
     };
     launch();  // warm-up

@@ -458,10 +458,18 @@ RT_DEV void trace_persistent(const SceneDev& sc, const Work& work, uint32_t n, u
     // through the device-wide cursor in small chunks, so waves that finish their share early take over work from slow
     // ones and the grid runs down together. Without a cursor the whole list is static.
     uint32_t chunk_pos = 0, chunk_end = 0;                                   // wave-uniform
-    uint32_t next_static = ((blockIdx.x * kTraceBlock + threadIdx.x) >> 6) * kChunk;
+    const uint32_t wave_id = (blockIdx.x * kTraceBlock + threadIdx.x) >> 6;
+    uint32_t next_static = wave_id * kChunk;
     const uint32_t static_stride = (gridDim.x * kTraceBlock >> 6) * kChunk;
     const uint32_t n_static = cursor ? ((n - (n >> RT_TAIL_SHIFT)) / kChunk) * kChunk : n;
     bool static_done = false;
+    // The dynamic part [n_static, n) can be cut into kTailCursors segments, each with a cursor of its own in its own 256-byte
+    // block (a wave starts at segment (wave mod kTailCursors) and moves on when a segment is used up). Returning atomics on
+    // one address are served one at a time, about 90 per microsecond on this chip, and a 20-frame launch asks for nearly
+    // that while it runs down; measured, though, 8 or 16 cursors make extend 2 % faster on its own and the whole frame 4 %
+    // slower when extend and connect overlap (5315 vs 5110 Mrays/s, four alternating runs each), so the default is one.
+    const uint32_t seg_len = cursor ? (((n - n_static) + kTailCursors * RT_TAIL_CHUNK - 1u) / (kTailCursors * RT_TAIL_CHUNK)) * RT_TAIL_CHUNK : 0u;
+    uint32_t seg = wave_id % kTailCursors, segs_empty = 0;
     for (;;) {
         unsigned long long idle = __builtin_amdgcn_ballot_w64(!live);
         uint32_t n_idle = uint32_t(__popcll(idle));
@@ -474,14 +482,23 @@ RT_DEV void trace_persistent(const SceneDev& sc, const Work& work, uint32_t n, u
                     if (chunk_pos >= n_static) static_done = true;
                 }
                 if (static_done) {
-                    uint32_t base = n;
-                    if (cursor) {
-                        if (lane == 0) base = n_static + atomicAdd(cursor, uint32_t(RT_TAIL_CHUNK));
-                        base = __shfl(base, 0);
+                    chunk_pos = chunk_end = 0;
+                    while (cursor && segs_empty < kTailCursors) {
+                        uint32_t off = seg_len;
+                        if (lane == 0) off = atomicAdd(cursor + seg * kCounterStride, uint32_t(RT_TAIL_CHUNK));
+                        off = __shfl(off, 0);
+                        const uint32_t seg_begin = n_static + seg * seg_len;
+                        const uint32_t seg_end = seg_begin + seg_len < n ? seg_begin + seg_len : n;
+                        if (off < seg_len && seg_begin + off < seg_end) {
+                            chunk_pos = seg_begin + off;
+                            chunk_end = chunk_pos + RT_TAIL_CHUNK < seg_end ? chunk_pos + RT_TAIL_CHUNK : seg_end;
+                            segs_empty = 0;
+                            break;
+                        }
+                        seg = seg + 1u == kTailCursors ? 0u : seg + 1u;
+                        ++segs_empty;
                     }
-                    chunk_pos = base;
-                    chunk_end = base + RT_TAIL_CHUNK < n ? base + RT_TAIL_CHUNK : n;
-                    if (base >= n) { drained = true; chunk_pos = chunk_end = 0; }
+                    if (chunk_pos >= chunk_end) { drained = true; chunk_pos = chunk_end = 0; }
                 }
             }
             uint32_t avail = chunk_end - chunk_pos;

@@ -33,6 +33,9 @@ constexpr uint32_t kTraceBlock = RT_TRACE_BLOCK;   // workgroup size of the trav
 #ifndef RT_TAIL_CHUNK
 #define RT_TAIL_CHUNK 64
 #endif
+#ifndef RT_TAIL_CURSORS
+#define RT_TAIL_CURSORS 1
+#endif
 #ifndef RT_COOP_ANYHIT
 #define RT_COOP_ANYHIT 0
 #endif
@@ -85,6 +88,8 @@ constexpr uint32_t kQueueShards = 64;
 #define RT_COUNTER_STRIDE 64
 #endif
 constexpr uint32_t kCounterStride = RT_COUNTER_STRIDE;
+constexpr uint32_t kTailCursors = RT_TAIL_CURSORS;   // work cursors per traversal launch, kCounterStride words apart
+constexpr uint32_t kCursorSetWords = kTailCursors * kCounterStride;
 
 // State of the paths of one bounce, three 16-byte records per path, indexed by queue position.
 struct PathDev {
