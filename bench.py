@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--eighth-child", action="store_true", help=argparse.SUPPRESS)   # internal: run only the 32-CU leg
     ap.add_argument("--exact-order", action="store_true", help="RT_EXACT_ORDER: the reference's tree and visiting order (bit-exact ids) instead of the default compressed 4-wide tree")
     ap.add_argument("--exact-arith", action="store_true", help="RT_EXACT_ARITH: shade stage with correctly rounded division / square root and no FMA (implied by --exact-order)")
+    ap.add_argument("--profile-context", choices=("timing", "overlapped"), default=None,
+                    help="profiling runs (tools/profile_r3.sh): timing = only the single-stream context that times every launch "
+                         "(two passes of --steps frames); overlapped = only the timed region's context")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--frames-per-pass", type=int, default=0)
     ap.add_argument("--partition", choices=("samples", "tiles"), default="samples",
@@ -73,6 +76,133 @@ def launch_ranks(n):
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     print(f"[bench] --gpus {n} without a launcher: starting {n} ranks through torch.distributed.run (port {port})", file=sys.stderr, flush=True)
     return subprocess.run(cmd).returncode
+
+
+def kernel_source_hash():
+    """Hash of everything the device code of librt_hip.so is built from (sources + compiler flags)."""
+    import hashlib
+    from ray_tracer_amd import build as rtbuild
+    h = hashlib.sha256()
+    for f in sorted(p for p in list(rtbuild.SOURCES) + list(rtbuild.HEADERS) if p.suffix in (".hip", ".h")):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    h.update(" ".join(rtbuild.FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
+def measure_kernels(rt, api, scene, args, device, base_flags):
+    """One pass of the timed region's size in a counting context (work per launch) and two in a context that brackets every
+    launch with HIP events on its own stream (times of kernels running alone; the second pass is the one reported)."""
+    lanes = int(os.environ.get("RT_HIP_LANES", "1"))
+    fpp = args.frames_per_pass or 32
+    k = max(1, min(fpp, -(-args.steps // max(1, lanes))))
+    rc = rt.HipRenderer.create(scene, max_bounces=args.bounces, device=device, flags=api.RT_COUNT_TRAVERSAL | base_flags,
+                               frames_per_pass=args.frames_per_pass)
+    rc.render(k)
+    c = rc.counters()
+    rc.destroy()
+    rtm = rt.HipRenderer.create(scene, max_bounces=args.bounces, device=device, flags=api.RT_KERNEL_TIMING | base_flags,
+                                frames_per_pass=args.frames_per_pass)
+    rtm.render(k)                # warm-up with a pass of the same size, so every timed launch is comparable
+    rtm.reset_accumulator()
+    rtm.render(k)
+    tm = rtm.last_timer_perf()
+    rtm.destroy()
+    return c, tm, k
+
+
+N_CU, SIMD_PER_CU, ISSUE_CYCLES_PER_WAVE_INSTR = 256, 4, 2     # a wave64 vector-ALU instruction occupies its SIMD (32 lanes wide) for 2 cycles
+
+
+def roofline_blocks(args, scene, c, tm, k):
+    prof, stale = {}, None
+    tag = {"atrium": "", "interior": "_interior", "car": "_car", "glass_blob": "_glass"}.get(args.scene)
+    std_size = (3840, 2160) if args.scene == "interior" else (1920, 1080)
+    default_cfg = (tag is not None and args.scale == 1.0 and (args.width, args.height) == std_size and args.bounces == 8
+                   and args.frames_per_pass == 0 and args.bvh == "spatial" and not args.exact_order and not args.exact_arith)
+    pfile = ROOT / "profiles" / f"r3_roofline_counters{tag or ''}.json"
+    if default_cfg and pfile.exists():
+        prof = json.loads(pfile.read_text())
+        stale = prof.get("kernel_source_hash") != kernel_source_hash()
+        if stale:
+            prof = {"source": prof.get("source"), "kernel_source_hash": prof.get("kernel_source_hash")}
+    any_hit = not bool((scene.materials["spec_trans"] > 0.5).any())      # shadow rays may stop at the first hit
+    wide = any_hit and args.exact_order                                   # 112-byte records only under RT_EXACT_ORDER
+    items = {"k_extend": c["extend_rays"], "k_shade": c["extend_rays"], "k_connect": c["shadow_rays"]}
+    ms = {"k_extend": tm["extend_ms"], "k_shade": tm["shade_ms"], "k_connect": tm["connect_ms"]}
+    launches = {"k_extend": tm["extend_launches"], "k_shade": tm["shade_launches"], "k_connect": tm["connect_launches"]}
+    algo = {"k_extend": algorithmic_bytes_extend(c["extend_rays"], c["extend_node_pops"], c["extend_tri_tests"]),
+            "k_connect": algorithmic_bytes_connect(c["shadow_rays"], c["shadow_node_pops"], c["shadow_tri_tests"], wide),
+            "k_shade": c["extend_rays"] * 380.0}
+    clock_ghz = prof.get("shader_clock_ghz_measured")
+    issue_peak = N_CU * SIMD_PER_CU * clock_ghz * 1e9 / ISSUE_CYCLES_PER_WAVE_INSTR if clock_ghz else None     # wave-instructions per second
+    per_kernel = {}
+    for kn in ("k_extend", "k_connect", "k_shade"):
+        sec = ms[kn] / 1e3
+        p = prof.get(kn, {})
+        n_l = max(1, launches[kn])
+        e = {"avg_launch_ms": ms[kn] / n_l, "launches": launches[kn], "items_per_launch": items[kn] / n_l,
+             "item": "vertex" if kn == "k_shade" else "ray",
+             "mitems_per_s": items[kn] / sec / 1e6 if sec > 0 else 0.0,
+             "algorithmic_bytes_per_launch": algo[kn] / n_l,
+             "achieved_algorithmic_GBs": algo[kn] / sec / 1e9 if sec > 0 else 0.0,
+             # from the committed counter passes (null when they were taken from other kernel sources)
+             "valu_wave_instr_per_s": None, "valu_issue_frac": None, "lanes_active_per_valu_instr": None, "lane_frac": None,
+             "traffic_bytes_per_launch": None, "fabric_GBs": None, "hbm_frac_upper_bound": None}
+        if p and sec > 0 and issue_peak:
+            traffic = p["fabric_bytes_per_item"] * items[kn]            # bytes beyond L2 for the work this run did
+            valu = p["valu_wave_instr_per_item"] * items[kn]
+            e.update({"valu_wave_instr_per_item": p["valu_wave_instr_per_item"], "valu_wave_instr_per_s": valu / sec,
+                      "valu_issue_frac": valu / sec / issue_peak,
+                      "lanes_active_per_valu_instr": p["lanes_active_per_valu_instr"],
+                      "lane_frac": valu / sec / issue_peak * p["lanes_active_per_valu_instr"] / 64.0,
+                      "traffic_bytes_per_launch": traffic / n_l, "fabric_GBs": traffic / sec / 1e9,
+                      "hbm_frac_upper_bound": traffic / sec / 1e9 / HBM_PEAK_GBS,
+                      "valu_issue_frac_profiled": p.get("valu_issue_frac"),
+                      "ta_busy_frac": p["ta_busy_frac"], "td_busy_frac": p["td_busy_frac"],
+                      "td_stalled_on_cache_frac": p["td_stalled_on_cache_frac"], "l2_hit_rate": p["l2_hit_rate"],
+                      "profiled_avg_launch_us": p.get("trace_avg_launch_us")})
+        per_kernel[kn] = e
+    ext = per_kernel["k_extend"]
+    out = {}
+    out["roofline"] = {
+        "kernel": "k_extend",
+        # The roof that binds is vector-ALU issue (a divergent gather of 64-byte records plus fp32 box / triangle tests: no
+        # MFMA work, and HBM far from its limit), so `achieved` / `peak` are vector-ALU wave-instructions per second.
+        "bound": "valu_issue", "unit": "wave-instructions/s",
+        "achieved": ext["valu_wave_instr_per_s"], "peak": issue_peak, "frac": ext["valu_issue_frac"],
+        "peak_note": f"{N_CU} CUs x {SIMD_PER_CU} SIMDs x measured shader clock / {ISSUE_CYCLES_PER_WAVE_INSTR} cycles per wave64 instruction",
+        "shader_clock_ghz_measured": clock_ghz,
+        "lanes_active_per_valu_instr": ext["lanes_active_per_valu_instr"], "lane_frac": ext["lane_frac"],
+        "traffic": ext["traffic_bytes_per_launch"],
+        # secondary: the memory side. Bytes that left L2 (Infinity-Cache hits included) per second bound HBM traffic from above.
+        "hbm_upper_bound": {"achieved_GBs": ext["fabric_GBs"], "peak_GBs": HBM_PEAK_GBS, "frac": ext["hbm_frac_upper_bound"]},
+        "achieved_algorithmic_GBs": ext["achieved_algorithmic_GBs"],
+        "achieved_algorithmic_note": "bytes a one-thread-per-ray loop would request (64 B per interior node visit, 48 B per triangle test, "
+                                     "80 B per ray) per second; most are served from LDS-resident records and L2, so this figure "
+                                     "exceeds the HBM peak by construction and is reported for continuity only",
+        "bytes_per_launch": ext["algorithmic_bytes_per_launch"], "avg_launch_ms": ext["avg_launch_ms"], "launches": ext["launches"],
+        "samples": k,
+        "counters_from": f"profiles/{pfile.name}" if prof else None, "counters_source_run": prof.get("source"),
+        "counters_stale": stale, "counters_launch_frames": prof.get("launch_frames"),
+        "live_in_this_run": ["avg_launch_ms", "launches", "items_per_launch", "algorithmic bytes", "node_pops_per_ray", "tri_tests_per_ray"],
+        "from_committed_profile": ["valu_wave_instr_per_item", "lanes_active_per_valu_instr", "fabric bytes per item", "shader clock",
+                                   "ta / td busy", "l2_hit_rate"],
+        "tree": "binary, reference order (RT_EXACT_ORDER)" if args.exact_order else "compressed 4-wide",
+        "node_pops_per_ray": c["extend_node_pops"] / max(1, c["extend_rays"]),
+        "tri_tests_per_ray": c["extend_tri_tests"] / max(1, c["extend_rays"]),
+        "extend_mrays_per_s": ext["mitems_per_s"],
+        "occupancy": "8 waves/SIMD (64 VGPRs; two 1024-thread workgroups per CU, 80 KiB LDS each)",
+    }
+    out["roofline_kernels"] = per_kernel
+    out["kernel_ms_per_sample"] = {s_: tm[f"{s_}_ms"] / k for s_ in ("raygen", "extend", "shade", "connect", "accumulate")}
+    out["kernel_ms_per_sample"]["total"] = tm["total_ms"] / k
+    out["shade_arithmetic"] = "exact (RT_EXACT_ARITH)" if (args.exact_arith or args.exact_order) else "fast (hardware rcp/rsq/sqrt, FMA contraction)"
+    out["connect"] = {"mrays_per_s": per_kernel["k_connect"]["mitems_per_s"],
+                      "tree": ("4-wide" if wide else ("binary" if args.exact_order else "compressed 4-wide")) + (", any hit" if any_hit else ", closest hit (glass rule)"),
+                      "node_pops_per_ray": c["shadow_node_pops"] / max(1, c["shadow_rays"]),
+                      "tri_tests_per_ray": c["shadow_tri_tests"] / max(1, c["shadow_rays"])}
+    return out
 
 
 def main():
@@ -150,6 +280,25 @@ def main():
                           "mrays_per_sec": (c8["extend_rays"] + c8["shadow_rays"]) / e8 / 1e6, "samples_per_sec": args.steps / e8,
                           "steps": args.steps, "warmup": args.warmup}), flush=True)
         return      # a normal interpreter exit, the HIP runtime's exit handler included (the parent notices if it does not return)
+
+    if args.profile_context == "timing":
+        # Profiling runs only: the single-stream context whose launches are bracketed by HIP events, two passes of --steps
+        # frames, nothing else on the GPU, so that every traced or counted launch is one of these. Prints what the passes did.
+        rtm = rt.HipRenderer.create(scene, max_bounces=args.bounces, device=local_rank, flags=api.RT_KERNEL_TIMING | base_flags,
+                                    frames_per_pass=args.frames_per_pass)
+        rtm.render(args.steps)
+        rtm.reset_accumulator()
+        rtm.render(args.steps)
+        tm = rtm.last_timer_perf()
+        cnt = rtm.counters()
+        rtm.destroy()
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps({"profile_context": "timing", "passes": 2, "steps": args.steps, "extend_rays": cnt["extend_rays"], "shadow_rays": cnt["shadow_rays"],
+                          "workload": f"{scene.name} {args.width}x{args.height}, {args.bounces} bounces", "kernel_source_hash": kernel_source_hash(),
+                          "last_pass_ms": {s_: tm[f"{s_}_ms"] for s_ in ("raygen", "extend", "shade", "connect", "accumulate", "total")},
+                          "last_pass_launches": {s_: tm[f"{s_}_launches"] for s_ in ("extend", "shade", "connect")}}), flush=True)
+        return
 
     # BVH build-time baseline (stand-in for the reference's criterion bench, benches/bvh.rs:11-40: clone the triangles,
     # build, 10 samples): median wall time of the library's builders on this scene (binned SAH, binned SAH with
@@ -272,96 +421,19 @@ def main():
     if rehearse and world > 1:
         result["rehearsal"] = f"{world} ranks sharing GPU 0, collectives over gloo: exercises the N > 1 code path, not a measurement"
 
-    # ---- per-kernel resource fractions, rank 0 only. Times are measured live (HIP events around every launch, on the stream
-    # the kernels run on, in a context that runs one pass of the size the timed region used); rays / vertices per launch come
-    # from the library's counters; bytes and instruction counts PER RAY come from the committed rocprofv3 counter passes of
-    # this same workload at this same launch size (tools/profile_r2.sh -> tools/roofline_counters.py), scaled by the rays
-    # this run's launches actually processed. Counters cannot be read from inside this process.
+    # ---- per-kernel resource fractions, rank 0 only. Measured live in this run: kernel times (HIP events around every launch,
+    # on the stream the kernels run on, in a context that runs one pass of the size the timed region used) and rays / vertices /
+    # node visits per launch (the library's counters). NOT measurable from inside this process: hardware counters. The
+    # per-ray instruction counts, lane utilisation, bytes beyond L2 and the shader clock come from the committed rocprofv3
+    # passes of this same workload at this same launch size (tools/profile_r3.sh -> tools/roofline_counters.py ->
+    # profiles/r3_roofline_counters*.json), and are used only while the hash of the kernel sources stored in that file equals
+    # the hash of the sources this library was built from; otherwise the line says "counters_stale" and carries nulls.
     note(f"timed region done: {elapsed * 1e3 / args.steps:.2f} ms per step")
+    if args.profile_context == "overlapped":
+        args.no_roofline = True
     if rank == 0 and not args.no_roofline:
-        lanes = int(os.environ.get("RT_HIP_LANES", "1"))
-        fpp = args.frames_per_pass or 32
-        k = max(1, min(fpp, -(-args.steps // max(1, lanes))))
-        rc = rt.HipRenderer.create(scene, max_bounces=args.bounces, device=local_rank, flags=api.RT_COUNT_TRAVERSAL | base_flags,
-                                   frames_per_pass=args.frames_per_pass)
-        rc.render(k)
-        c = rc.counters()
-        rc.destroy()
-        rtm = rt.HipRenderer.create(scene, max_bounces=args.bounces, device=local_rank, flags=api.RT_KERNEL_TIMING | base_flags,
-                                    frames_per_pass=args.frames_per_pass)
-        rtm.render(k)                # warm-up with a pass of the same size, so every timed launch is comparable
-        rtm.reset_accumulator()
-        rtm.render(k)
-        tm = rtm.last_timer_perf()
-        rtm.destroy()
-        prof = {}
-        pfile = ROOT / "profiles" / "r2_roofline_counters.json"
-        default_cfg = (args.scene == "atrium" and args.scale == 1.0 and (args.width, args.height, args.bounces) == (1920, 1080, 8)
-                       and args.frames_per_pass == 0 and args.bvh == "spatial")
-        if default_cfg and pfile.exists():
-            prof = json.loads(pfile.read_text())
-        any_hit = not bool((scene.materials["spec_trans"] > 0.5).any())      # shadow rays may stop at the first hit
-        wide = any_hit and args.exact_order                                   # 112-byte records only under RT_EXACT_ORDER
-        items = {"k_extend": c["extend_rays"], "k_shade": c["extend_rays"], "k_connect": c["shadow_rays"]}
-        ms = {"k_extend": tm["extend_ms"], "k_shade": tm["shade_ms"], "k_connect": tm["connect_ms"]}
-        launches = {"k_extend": tm["extend_launches"], "k_shade": tm["shade_launches"], "k_connect": tm["connect_launches"]}
-        algo = {"k_extend": algorithmic_bytes_extend(c["extend_rays"], c["extend_node_pops"], c["extend_tri_tests"]),
-                "k_connect": algorithmic_bytes_connect(c["shadow_rays"], c["shadow_node_pops"], c["shadow_tri_tests"], wide),
-                "k_shade": c["extend_rays"] * 380.0}
-        # issue cost of the kernels' instruction mix, from tools/micro/valu_rate.hip on this chip (profiles/r1_micro_valu_rate.txt):
-        # mul/sub/fma/cvt 2.6-2.8 cycles per wave-instruction per SIMD, cmp+cndmask 3.85, min3/max3 4.4-4.6; the traversal
-        # loops are about 60 % / 25 % / 15 % of those, the shade kernel mostly the first kind
-        mix_cycles = {"k_extend": 3.2, "k_connect": 3.2, "k_shade": 2.9}
-        per_kernel = {}
-        for kn in ("k_extend", "k_connect", "k_shade"):
-            sec = ms[kn] / 1e3
-            p = prof.get(kn, {})
-            n_l = max(1, launches[kn])
-            e = {"avg_launch_ms": ms[kn] / n_l, "launches": launches[kn], "items_per_launch": items[kn] / n_l,
-                 "item": "vertex" if kn == "k_shade" else "ray",
-                 "mitems_per_s": items[kn] / sec / 1e6 if sec > 0 else 0.0,
-                 "algorithmic_bytes_per_launch": algo[kn] / n_l,
-                 "achieved_algorithmic_GBs": algo[kn] / sec / 1e9 if sec > 0 else 0.0}
-            if p and sec > 0:
-                traffic = p["fabric_bytes_per_item"] * items[kn]            # bytes beyond L2 for the work this run did
-                valu = p["valu_wave_instr_per_item"] * items[kn]
-                cu_cycles = 256 * 2.4e9 * sec                               # upper bound on the cycles available (2.4 GHz peak clock)
-                e.update({"traffic_bytes_per_launch": traffic / n_l, "fabric_GBs": traffic / sec / 1e9,
-                          "hbm_frac_upper_bound": traffic / sec / 1e9 / HBM_PEAK_GBS,
-                          "valu_wave_instr_per_item": p["valu_wave_instr_per_item"],
-                          "valu_issue_frac": valu * mix_cycles[kn] / 4.0 / cu_cycles,
-                          "valu_wave_instr_per_cu_cycle_profiled": p["valu_wave_instr_per_cu_cycle"],
-                          "lanes_active_per_valu_instr": p["lanes_active_per_valu_instr"],
-                          "ta_busy_frac": p["ta_busy_frac"], "td_busy_frac": p["td_busy_frac"],
-                          "td_stalled_on_cache_frac": p["td_stalled_on_cache_frac"], "l2_hit_rate": p["l2_hit_rate"]})
-            per_kernel[kn] = e
-        ext = per_kernel["k_extend"]
-        result["roofline"] = {
-            "kernel": "k_extend", "bound": "hbm",
-            # bytes that left L2 (Infinity-Cache hits included) per second: an upper bound on what the kernel asks of HBM
-            "achieved": ext.get("fabric_GBs"), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ext.get("hbm_frac_upper_bound"),
-            "traffic": ext.get("traffic_bytes_per_launch"),
-            "limited_by": "vector-ALU issue (valu_issue_frac) together with the CU's vector-memory return path (td_busy_frac); HBM is far from its limit",
-            "valu_issue_frac": ext.get("valu_issue_frac"), "ta_busy_frac": ext.get("ta_busy_frac"), "td_busy_frac": ext.get("td_busy_frac"),
-            "achieved_algorithmic": ext["achieved_algorithmic_GBs"],
-            "achieved_algorithmic_note": "bytes a one-thread-per-ray loop would request (64 B per interior node visit, 48 B per triangle test, "
-                                         "80 B per ray) per second; most of them are served from LDS-resident records and L2, so this "
-                                         "figure is not bounded by the HBM peak and is reported for continuity only",
-            "bytes_per_launch": ext["algorithmic_bytes_per_launch"], "avg_launch_ms": ext["avg_launch_ms"], "launches": ext["launches"],
-            "samples": k, "counters_from": prof.get("source"), "counters_launch_frames": prof.get("launch_frames"),
-            "tree": "binary, reference order (RT_EXACT_ORDER)" if args.exact_order else "compressed 4-wide",
-            "node_pops_per_ray": c["extend_node_pops"] / max(1, c["extend_rays"]),
-            "tri_tests_per_ray": c["extend_tri_tests"] / max(1, c["extend_rays"]),
-            "extend_mrays_per_s": ext["mitems_per_s"],
-            "occupancy": "8 waves/SIMD (64 VGPRs; two 1024-thread workgroups per CU, 80 KiB LDS each)",
-        }
-        result["roofline_kernels"] = per_kernel
-        result["kernel_ms_per_sample"] = {s_: tm[f"{s_}_ms"] / k for s_ in ("raygen", "extend", "shade", "connect", "accumulate")}
-        result["kernel_ms_per_sample"]["total"] = tm["total_ms"] / k
-        result["connect"] = {"mrays_per_s": per_kernel["k_connect"]["mitems_per_s"],
-                             "tree": ("4-wide" if wide else ("binary" if args.exact_order else "compressed 4-wide")) + (", any hit" if any_hit else ", closest hit (glass rule)"),
-                             "node_pops_per_ray": c["shadow_node_pops"] / max(1, c["shadow_rays"]),
-                             "tri_tests_per_ray": c["shadow_tri_tests"] / max(1, c["shadow_rays"])}
+        c, tm, k = measure_kernels(rt, api, scene, args, local_rank, base_flags)
+        result.update(roofline_blocks(args, scene, c, tm, k))
 
     # ---- "1/8 MI355X", measured: the same workload with every stream of the context confined to 32 of the 256 compute units.
     # Caches and HBM are not partitioned, so this bounds a true one-eighth partition from above; `value_div_8` is the plain
