@@ -424,8 +424,9 @@ RT_DEV void leaf_phase(const SceneDev& sc, LaneRay& r, unsigned long long parked
 }
 
 // Work description for the persistent tracer: how item i becomes a ray and where its result goes.
-//   uint32_t load(uint32_t i, f3& o, f3& d, float& tmax)  -- tmax is the initial "closest so far"; returns a handle
-//                                                            (where the item lives) that store() gets back
+//   void run_of(uint32_t i, uint32_t& lo, uint32_t& hi, uint32_t& base)  -- items [lo, hi) around i live at handles base + (item - lo)
+//   void load(uint32_t handle, f3& o, f3& d, float& tmax)  -- tmax is the initial "closest so far"; store() gets the
+//                                                            same handle back
 // ANYHIT turns the closest-hit search into an occlusion query (stop at the first hit below tmax).
 //   void store(uint32_t handle, const LaneRay& r)
 // TREE: which tree is walked. kTreeBinary: the reference's binary tree in the reference's order (bit-identical ids).
@@ -470,6 +471,7 @@ RT_DEV void trace_persistent(const SceneDev& sc, const Work& work, uint32_t n, u
     // slower when extend and connect overlap (5315 vs 5110 Mrays/s, four alternating runs each), so the default is one.
     const uint32_t seg_len = cursor ? (((n - n_static) + kTailCursors * RT_TAIL_CHUNK - 1u) / (kTailCursors * RT_TAIL_CHUNK)) * RT_TAIL_CHUNK : 0u;
     uint32_t seg = wave_id % kTailCursors, segs_empty = 0;
+    uint32_t run_lo = 1u, run_hi = 0u, run_base = 0u;                        // wave-uniform: where the items around chunk_pos live (empty at first)
     for (;;) {
         unsigned long long idle = __builtin_amdgcn_ballot_w64(!live);
         uint32_t n_idle = uint32_t(__popcll(idle));
@@ -503,10 +505,18 @@ RT_DEV void trace_persistent(const SceneDev& sc, const Work& work, uint32_t n, u
             }
             uint32_t avail = chunk_end - chunk_pos;
             uint32_t rank = uint32_t(__popcll(idle & ((1ull << lane) - 1ull)));
+            if (avail != 0u && (chunk_pos < run_lo || chunk_pos >= run_hi)) work.run_of(chunk_pos, run_lo, run_hi, run_base);
             if (!live && rank < avail) {
                 uint32_t mine = chunk_pos + rank;
+                if (__builtin_expect(mine >= run_hi, 0)) {                   // the chunk runs on into the next region
+                    uint32_t lo2, hi2, base2;
+                    work.run_of(mine, lo2, hi2, base2);
+                    r.item = base2 + (mine - lo2);
+                } else {
+                    r.item = run_base + (mine - run_lo);
+                }
                 float tmax;
-                r.item = work.load(mine, r.o, r.d, tmax);
+                work.load(r.item, r.o, r.d, tmax);
                 r.inv = f3{1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z};
                 r.t = tmax; r.u = 0.0f; r.v = 0.0f; r.prim = kNoPrim;
                 r.sp = 0;
@@ -668,12 +678,11 @@ struct ExtendWork {
     PathDev pd;
     float4* __restrict__ hit;     // {t, u, v, prim bits} per queue position
     RegionMap map;
-    RT_DEV uint32_t load(uint32_t i, f3& o, f3& d, float& tmax) const {
-        const uint32_t p = map(i);
+    RT_DEV void run_of(uint32_t i, uint32_t& lo, uint32_t& hi, uint32_t& base) const { map.run_of(i, lo, hi, base); }
+    RT_DEV void load(uint32_t p, f3& o, f3& d, float& tmax) const {
         o = xyz(pd.o[p]);
         d = xyz(pd.d[p]);
         tmax = INFINITY;
-        return p;
     }
     RT_DEV void store(uint32_t p, const LaneRay& r) const { hit[p] = make_float4(r.t, r.u, r.v, __uint_as_float(r.prim)); }
 };
@@ -685,13 +694,12 @@ struct ConnectWork {
     ShadowDev sq;
     float4* __restrict__ rad;     // per slot {radiance rgb, -}
     RegionMap map;
-    RT_DEV uint32_t load(uint32_t i, f3& o, f3& d, float& tmax) const {
-        const uint32_t p = map(i);
+    RT_DEV void run_of(uint32_t i, uint32_t& lo, uint32_t& hi, uint32_t& base) const { map.run_of(i, lo, hi, base); }
+    RT_DEV void load(uint32_t p, f3& o, f3& d, float& tmax) const {
         float4 o4 = sq.o[p];
         o = xyz(o4);
         d = xyz(sq.d[p]);
         tmax = o4.w;
-        return p;
     }
     RT_DEV void store(uint32_t p, const LaneRay& r) const {
         bool blocked = false;
@@ -870,12 +878,12 @@ struct RayListWork {
     const float4* __restrict__ rd;
     float4* __restrict__ hits;
     int shadow;
-    RT_DEV uint32_t load(uint32_t i, f3& o, f3& d, float& tmax) const {
+    RT_DEV void run_of(uint32_t, uint32_t& lo, uint32_t& hi, uint32_t& base) const { lo = 0u; hi = 0xFFFFFFFFu; base = 0u; }
+    RT_DEV void load(uint32_t i, f3& o, f3& d, float& tmax) const {
         float4 o4 = ro[i];
         o = xyz(o4);
         d = xyz(rd[i]);
         tmax = shadow ? o4.w : INFINITY;
-        return i;
     }
     RT_DEV void store(uint32_t i, const LaneRay& r) const {
         if (shadow) {
@@ -911,11 +919,11 @@ struct PackedRayWork {
     const float* __restrict__ o3;
     const float* __restrict__ d3;
     float4* __restrict__ hits;
-    RT_DEV uint32_t load(uint32_t i, f3& o, f3& d, float& tmax) const {
+    RT_DEV void run_of(uint32_t, uint32_t& lo, uint32_t& hi, uint32_t& base) const { lo = 0u; hi = 0xFFFFFFFFu; base = 0u; }
+    RT_DEV void load(uint32_t i, f3& o, f3& d, float& tmax) const {
         o = f3{o3[3 * size_t(i)], o3[3 * size_t(i) + 1], o3[3 * size_t(i) + 2]};
         d = f3{d3[3 * size_t(i)], d3[3 * size_t(i) + 1], d3[3 * size_t(i) + 2]};
         tmax = INFINITY;
-        return i;
     }
     RT_DEV void store(uint32_t i, const LaneRay& r) const { hits[i] = make_float4(r.t, r.u, r.v, __uint_as_float(r.prim)); }
 };

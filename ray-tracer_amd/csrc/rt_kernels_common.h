@@ -176,6 +176,16 @@ struct RegionMap {
             if (prefix[k + step] <= v) k += step;
         return k * cap + (v - prefix[k]);
     }
+    // The run of items around item v that lies in one region: items [lo, hi) live at positions base + (item - lo). Meant
+    // for a wave-uniform v: a wave that takes consecutive items looks its region up once and then places each item with
+    // one subtraction and one addition instead of a six-step search through LDS per item.
+    RT_DEV void run_of(uint32_t v, uint32_t& lo, uint32_t& hi, uint32_t& base) const {
+        if (identity) { lo = 0u; hi = 0xFFFFFFFFu; base = 0u; return; }
+        uint32_t k = 0;
+        for (uint32_t step = kQueueShards >> 1; step != 0; step >>= 1)
+            if (prefix[k + step] <= v) k += step;
+        lo = prefix[k]; hi = prefix[k + 1]; base = k * cap;
+    }
 };
 
 }  // namespace rtdev

@@ -89,8 +89,12 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_WAVES) void k_shade(SceneDev sc, P
         int probe_light = -1, probe_lobe = -1, probe_tri = -1;
         float probe_lpdf = 0.0f, probe_bpdf = 0.0f, probe_rough = 0.0f;
         f3 probe_thr = {0.0f, 0.0f, 0.0f};
+        // the 64 consecutive items of this wave nearly always lie in one region: one look-up for the wave, a per-lane
+        // search only for the lanes beyond the region's end
+        uint32_t run_lo, run_hi, run_base;
+        map.run_of(base, run_lo, run_hi, run_base);
         if (valid) {
-            pin = map(i);
+            pin = __builtin_expect(i < run_hi, 1) ? run_base + (i - run_lo) : map(i);
             float4 h4 = sp.hit[pin], o4 = pd.o[pin], d4 = pd.d[pin], T4 = pd.t[pin];
             f3 ro = xyz(o4), rd = xyz(d4), thr = xyz(T4);
             f3 rad = {0.0f, 0.0f, 0.0f};                   // what this vertex adds to the path's radiance
