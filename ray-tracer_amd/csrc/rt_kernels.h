@@ -690,7 +690,7 @@ struct ExtendWork {
 // Occluded = a closest hit nearer than tmax whose material is not glass-like (disney.comp:697-701,
 // intersects.comp:152-154). A path has at most one light sample per bounce, so the add to its slot needs no atomic.
 struct ConnectWork {
-    SceneDev sc;
+    const float4* __restrict__ tri_shade;   // the triangles' shading records: chunk 0 carries the glass bit (only that pointer, not the whole scene view, stays live through the traversal)
     ShadowDev sq;
     float4* __restrict__ rad;     // per slot {radiance rgb, -}
     RegionMap map;
@@ -703,7 +703,7 @@ struct ConnectWork {
     }
     RT_DEV void store(uint32_t p, const LaneRay& r) const {
         bool blocked = false;
-        if (r.prim != kNoPrim) blocked = (__float_as_uint(sc.shade[size_t(r.prim) * 4].w) & 0x80000000u) == 0u;
+        if (r.prim != kNoPrim) blocked = (__float_as_uint(tri_shade[size_t(r.prim) * 4].w) & 0x80000000u) == 0u;
         if (!blocked) {
             const uint32_t slot = __float_as_uint(sq.d[p].w);
             float4 c = sq.c[p];
@@ -756,7 +756,7 @@ __global__ __launch_bounds__(kTraceBlock, RT_TRACE_WAVES_PER_EU) void k_connect(
     RT_TRACE_LDS(TREE)
     const uint32_t n = load_region_prefix(rg, s_prefix);
     uint32_t n_node = 0, n_leaf = 0, n_tri = 0;
-    ConnectWork work{sc, sq, rad, RegionMap{(const lds_u32*)s_prefix, rg.cap, rg.counts == nullptr}};
+    ConnectWork work{sc.shade, sq, rad, RegionMap{(const lds_u32*)s_prefix, rg.cap, rg.counts == nullptr}};
     trace_persistent<COUNT, ANYHIT, TREE>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, (lds_u8*)s_owner + (threadIdx.x & ~63u), hot, n_node, n_leaf, n_tri,
                                           COUNT ? stats->visits[TREE == kTreeBinary ? 0 : 1] : nullptr);
     flush_counts<COUNT>(n_node, n_leaf, n_tri, &stats->shadow_node_pops, &stats->shadow_leaf_pops, &stats->shadow_tri_tests);
@@ -873,7 +873,7 @@ __global__ void k_finish_pass(const uint32_t* __restrict__ shard_counts, uint32_
 
 // ---- stage-level kernels on caller-supplied inputs -----------------------------------------------------
 struct RayListWork {
-    SceneDev sc;
+    const float4* __restrict__ tri_shade;
     const float4* __restrict__ ro;   // {origin, tmax when shadow}
     const float4* __restrict__ rd;
     float4* __restrict__ hits;
@@ -887,7 +887,7 @@ struct RayListWork {
     }
     RT_DEV void store(uint32_t i, const LaneRay& r) const {
         if (shadow) {
-            bool blocked = r.prim != kNoPrim && (__float_as_uint(sc.shade[size_t(r.prim) * 4].w) & 0x80000000u) == 0u;
+            bool blocked = r.prim != kNoPrim && (__float_as_uint(tri_shade[size_t(r.prim) * 4].w) & 0x80000000u) == 0u;
             hits[i] = make_float4(blocked ? 0.0f : 1.0f, 0.0f, 0.0f, __uint_as_float(r.prim));
         } else {
             hits[i] = make_float4(r.t, r.u, r.v, __uint_as_float(r.prim));
@@ -903,7 +903,7 @@ __global__ __launch_bounds__(kTraceBlock, RT_TRACE_WAVES_PER_EU) void k_trace_ra
     const int tree = FAST ? kTreeCw : (any_hit ? kTreeWide : kTreeBinary);
     RT_TRACE_LDS(tree)
     uint32_t n_node = 0, n_leaf = 0, n_tri = 0;
-    RayListWork work{sc, ro, rd, hits, shadow};
+    RayListWork work{sc.shade, ro, rd, hits, shadow};
     lds_u32* st = (lds_u32*)s_stack + threadIdx.x;
     lds_u8* ow = (lds_u8*)s_owner + (threadIdx.x & ~63u);
     if (any_hit && FAST) trace_persistent<COUNT, true, kTreeCw>(sc, work, n, cursor, st, ow, hot, n_node, n_leaf, n_tri);
