@@ -87,8 +87,10 @@ public:
         r.upload_scene(scene);
         return r;
     }
-    HipRenderer(HipRenderer&& o) noexcept : ctx_(std::exchange(o.ctx_, nullptr)) {}
-    HipRenderer& operator=(HipRenderer&& o) noexcept { destroy(); ctx_ = std::exchange(o.ctx_, nullptr); return *this; }
+    HipRenderer(HipRenderer&& o) noexcept : ctx_(std::exchange(o.ctx_, nullptr)), camera_in_use_(o.camera_in_use_), have_camera_(o.have_camera_) {}
+    HipRenderer& operator=(HipRenderer&& o) noexcept {
+        destroy(); ctx_ = std::exchange(o.ctx_, nullptr); camera_in_use_ = o.camera_in_use_; have_camera_ = o.have_camera_; return *this;
+    }
     HipRenderer(const HipRenderer&) = delete;
     HipRenderer& operator=(const HipRenderer&) = delete;
     ~HipRenderer() { destroy(); }
@@ -101,9 +103,18 @@ public:
         check(rt_upload_scene(ctx_, blob.data(), sz, uint32_t(scene.bvh.size()), uint32_t(scene.materials.size()),
                               uint32_t(scene.triangles.size()), uint32_t(scene.lights.size()), uint32_t(scene.emissive_tris.size())), ctx_);
         check(rt_set_camera(ctx_, &scene.camera), ctx_);
+        camera_in_use_ = scene.camera; have_camera_ = true;
     }
     // reload_scene (renderer.rs:193-231): the new scene is viewed from the current camera pose (location and rotation
     // are carried over, renderer.rs:194-196).
+    void reload_scene(Scene scene) {
+        if (have_camera_) {
+            for (int k = 0; k < 4; ++k) scene.camera.location[k] = camera_in_use_.location[k];
+            for (int k = 0; k < 16; ++k) scene.camera.rotation[k] = camera_in_use_.rotation[k];
+        }
+        upload_scene(scene);
+    }
+    // the same with the pose given by the caller
     void reload_scene(Scene scene, const rt_camera& current) {
         for (int k = 0; k < 4; ++k) scene.camera.location[k] = current.location[k];
         for (int k = 0; k < 16; ++k) scene.camera.rotation[k] = current.rotation[k];
@@ -113,7 +124,7 @@ public:
         check(rt_upload_textures(ctx_, textures.data(), uint32_t(textures.size()), skybox), ctx_);
     }
     // set_camera_pose (renderer.rs:165-168)
-    void set_camera(const rt_camera& cam) { check(rt_set_camera(ctx_, &cam), ctx_); }
+    void set_camera(const rt_camera& cam) { check(rt_set_camera(ctx_, &cam), ctx_); camera_in_use_ = cam; have_camera_ = true; }
     void reset_accumulator() { check(rt_reset_accumulation(ctx_), ctx_); }         // renderer.rs:170-177
     uint32_t sample_count() const { return rt_sample_count(ctx_); }                  // renderer.rs:180-182
     void handle_resize(uint32_t w, uint32_t h) { check(rt_resize(ctx_, w, h), ctx_); }   // renderer.rs:133-162
@@ -136,6 +147,8 @@ public:
 private:
     HipRenderer() = default;
     rt_ctx* ctx_ = nullptr;
+    rt_camera camera_in_use_{};      // what upload_scene / set_camera installed last: the pose reload_scene carries over
+    bool have_camera_ = false;
 };
 
 }  // namespace rt

@@ -320,12 +320,14 @@ int rt_trace_shadow(rt_ctx* ctx, uint32_t n, const float* origins, const float* 
 int rt_bench_trace(rt_ctx* ctx, uint32_t n, const float* origins, const float* directions, int shadow,
                    uint32_t repeat, float* ms_per_launch);
 
-/* rt_trace_closest for callers that may not allocate device memory: code running under HIP graph capture, tight serving
- * loops, harnesses that forbid hipMalloc. No counterpart in the reference. Same inputs, same outputs (bit for bit), but
- * the call allocates nothing: rays, hits and the work cursor are staged in one fixed device array that is part of the
- * library image (about 10 MiB per GPU, held until the process ends), which limits a call to RT_STATIC_MAX_RAYS rays;
- * more is refused with RT_ERR_UNSUPPORTED. All contexts on one GPU share that array: two such calls that overlap in
- * time on the same GPU race, so serialise them. Per-kernel timing (RT_KERNEL_TIMING) does not cover this call. */
+/* rt_trace_closest for callers that may not allocate device memory: tight serving loops, harnesses that forbid
+ * hipMalloc, processes in which another stream is being captured into a HIP graph. No counterpart in the reference. Same
+ * inputs, same outputs (bit for bit), but the call allocates no device memory: rays, hits and the work cursor are staged in
+ * one fixed device array that is part of the library image (about 10 MiB per GPU, held until the process ends), which
+ * limits a call to RT_STATIC_MAX_RAYS rays; more is refused with RT_ERR_UNSUPPORTED. The call is synchronous (it copies
+ * from and to the caller's host buffers on the context's own stream and waits for it), so it cannot itself be part of a
+ * captured graph. All contexts on one GPU share the array: two such calls that overlap in time on the same GPU race, so
+ * serialise them. Per-kernel timing (RT_KERNEL_TIMING) does not cover this call. */
 #define RT_STATIC_MAX_RAYS (1u << 18)
 int rt_trace_closest_static(rt_ctx* ctx, uint32_t n, const float* origins, const float* directions, rt_hit* hits);
 

@@ -35,8 +35,9 @@ using namespace rtbvh;
 constexpr size_t kSharedWorkMin = 8 * 1024;
 constexpr size_t kChunkParallelMin = 64 * 1024;
 
-// A build reference: a primitive with a (possibly clipped) box.
-struct Ref {
+// What the builder sorts: a triangle id with the part of its bounds that lies in the node being split (spatial splits
+// hand one triangle to both children, each with its own clipped part).
+struct Fragment {
     V3 lo, hi;
     uint32_t prim;
     V3 centroid() const { return vmul(vadd(lo, hi), 0.5f); }
@@ -107,7 +108,7 @@ struct TmpNode {
 struct Task {
     uint32_t slot = 0, depth = 0;
     int64_t budget = 0;
-    std::vector<Ref> refs;
+    std::vector<Fragment> refs;
     Box geom, cent;
 };
 
@@ -166,16 +167,16 @@ struct SpatialBuilder {
         arena[t.slot].count = uint32_t(ids.size());
     }
 
-    struct ObjCand { float cost; int axis, bin; Box lg, rg; };
-    struct SpatCand { float cost; int axis; float plane; };
+    struct ObjectSplit { float cost; int axis, bin; Box left_bounds, right_bounds; };
+    struct PlaneSplit { float cost; int axis; float plane; };
 
-    bool object_candidate(const Task& t, V3 scale, ObjCand& out) const {
+    bool object_candidate(const Task& t, V3 scale, ObjectSplit& out) const {
         size_t nc = chunks_for(t.refs.size());
         std::vector<ObjBins> part(nc);
         for_chunks(t.refs.size(), nc, [&](size_t b, size_t e, size_t c) {
             ObjBins& bins = part[c];
             for (size_t k = b; k < e; ++k) {
-                const Ref& r = t.refs[k];
+                const Fragment& r = t.refs[k];
                 int bi[3];
                 bin_of(r.centroid(), t.cent.lo, scale, bi);
                 for (int a = 0; a < 3; ++a) { bins.box[a][bi[a]].grow(r.lo, r.hi); bins.count[a][bi[a]]++; }
@@ -211,10 +212,10 @@ struct SpatialBuilder {
         out.cost = best;
         out.axis = best_axis;
         out.bin = best_bin;
-        out.lg = Box{};
-        out.rg = Box{};
-        for (int b = 0; b < best_bin; ++b) out.lg.grow(bins.box[best_axis][b].lo, bins.box[best_axis][b].hi);
-        for (int b = best_bin; b < kBins; ++b) out.rg.grow(bins.box[best_axis][b].lo, bins.box[best_axis][b].hi);
+        out.left_bounds = Box{};
+        out.right_bounds = Box{};
+        for (int b = 0; b < best_bin; ++b) out.left_bounds.grow(bins.box[best_axis][b].lo, bins.box[best_axis][b].hi);
+        for (int b = best_bin; b < kBins; ++b) out.right_bounds.grow(bins.box[best_axis][b].lo, bins.box[best_axis][b].hi);
         return true;
     }
 
@@ -222,7 +223,7 @@ struct SpatialBuilder {
     void spatial_bins(const Task& t, size_t b0, size_t e0, int axis, float base, float width, float inv, SpatBins& sb) const {
         const int top = kBins - 1;
         for (size_t k = b0; k < e0; ++k) {
-            const Ref& r = t.refs[k];
+            const Fragment& r = t.refs[k];
             int lo = clamp_bin((r.lo[axis] - base) * inv);
             int hi = std::max(clamp_bin((r.hi[axis] - base) * inv), lo);
             if (lo == hi) {
@@ -247,7 +248,7 @@ struct SpatialBuilder {
         (void)top;
     }
 
-    bool spatial_candidate(const Task& t, SpatCand& out) const {
+    bool spatial_candidate(const Task& t, PlaneSplit& out) const {
         V3 ext = vmax(vsub(t.geom.hi, t.geom.lo), V3{0, 0, 0});
         bool found = false;
         for (int axis = 0; axis < 3; ++axis) {
@@ -291,12 +292,12 @@ struct SpatialBuilder {
     }
 
     struct Side {
-        std::vector<Ref> refs;
+        std::vector<Fragment> refs;
         Box geom, cent;
         void push(V3 lo, V3 hi, uint32_t prim) {
             geom.grow(lo, hi);
             cent.grow(vmul(vadd(lo, hi), 0.5f));
-            refs.push_back(Ref{lo, hi, prim});
+            refs.push_back(Fragment{lo, hi, prim});
         }
     };
 
@@ -304,7 +305,7 @@ struct SpatialBuilder {
     bool distribute_spatial(const Task& t, int axis, float plane, int64_t& budget, Side& l, Side& r) const {
         l.refs.reserve(t.refs.size());
         r.refs.reserve(t.refs.size());
-        for (const Ref& rf : t.refs) {
+        for (const Fragment& rf : t.refs) {
             if (rf.hi[axis] <= plane) { l.push(rf.lo, rf.hi, rf.prim); continue; }
             if (rf.lo[axis] >= plane) { r.push(rf.lo, rf.hi, rf.prim); continue; }
             bool whole = true;
@@ -335,9 +336,9 @@ struct SpatialBuilder {
         return !l.refs.empty() && !r.refs.empty();
     }
 
-    static void bounds_of(const std::vector<Ref>& refs, Box& g, Box& c) {
+    static void bounds_of(const std::vector<Fragment>& refs, Box& g, Box& c) {
         g = Box{}; c = Box{};
-        for (const Ref& r : refs) { g.grow(r.lo, r.hi); c.grow(r.centroid()); }
+        for (const Fragment& r : refs) { g.grow(r.lo, r.hi); c.grow(r.centroid()); }
     }
 
     void median_split(Task& t, Side& l, Side& r) const {
@@ -346,7 +347,7 @@ struct SpatialBuilder {
         int axis = std::max(cext.x, std::max(cext.y, cext.z)) > 0.0f
                        ? widest_axis(cext)
                        : widest_axis(vmax(vsub(t.geom.hi, t.geom.lo), V3{0, 0, 0}));
-        std::nth_element(t.refs.begin(), t.refs.begin() + mid, t.refs.end(), [&](const Ref& p, const Ref& q) {
+        std::nth_element(t.refs.begin(), t.refs.begin() + mid, t.refs.end(), [&](const Fragment& p, const Fragment& q) {
             float a = (p.lo[axis] + p.hi[axis]) * 0.5f, b = (q.lo[axis] + q.hi[axis]) * 0.5f;
             if (a != b) return a < b;
             if (p.prim != q.prim) return p.prim < q.prim;
@@ -364,11 +365,11 @@ struct SpatialBuilder {
         if (n <= cfg.min_leaf || t.depth >= kMaxDepth) { emit_leaf(t); return; }
 
         V3 scale = bin_scale(t.cent);
-        ObjCand obj{};
+        ObjectSplit obj{};
         bool has_obj = (scale.x > 0.0f || scale.y > 0.0f || scale.z > 0.0f) && object_candidate(t, scale, obj);
 
-        bool try_spatial = t.budget > 0 && (!has_obj || intersect(obj.lg, obj.rg).half_area() / root_half > alpha);
-        SpatCand spa{};
+        bool try_spatial = t.budget > 0 && (!has_obj || intersect(obj.left_bounds, obj.right_bounds).half_area() / root_half > alpha);
+        PlaneSplit spa{};
         bool has_spa = try_spatial && spatial_candidate(t, spa);
 
         float parent_h = std::max(t.geom.half_area(), 1e-30f);
@@ -391,19 +392,19 @@ struct SpatialBuilder {
             else { l = Side{}; r = Side{}; }
         }
         if (!done && has_obj) {
-            for (const Ref& rf : t.refs) {
+            for (const Fragment& rf : t.refs) {
                 int bi[3];
                 bin_of(rf.centroid(), t.cent.lo, scale, bi);
                 Side& s = bi[obj.axis] < obj.bin ? l : r;
                 s.refs.push_back(rf);
                 s.cent.grow(rf.centroid());
             }
-            if (!l.refs.empty() && !r.refs.empty()) { l.geom = obj.lg; r.geom = obj.rg; done = true; }
+            if (!l.refs.empty() && !r.refs.empty()) { l.geom = obj.left_bounds; r.geom = obj.right_bounds; done = true; }
             else { l = Side{}; r = Side{}; }
         }
         if (!done) median_split(t, l, r);
 
-        std::vector<Ref>().swap(t.refs);
+        std::vector<Fragment>().swap(t.refs);
         uint32_t pair = arena_used.fetch_add(2);
         arena[t.slot].box = t.geom;
         arena[t.slot].first = pair;
@@ -508,7 +509,7 @@ extern "C" int rt_bvh_build_spatial(const rt_triangle* tris, uint32_t n_tri, con
     for (uint32_t i = 0; i < n_tri; ++i) {
         const rt_triangle& t = tris[i];
         V3 a{t.v[0][0], t.v[0][1], t.v[0][2]}, c{t.v[1][0], t.v[1][1], t.v[1][2]}, d{t.v[2][0], t.v[2][1], t.v[2][2]};
-        Ref r{vmin(a, vmin(c, d)), vmax(a, vmax(c, d)), i};
+        Fragment r{vmin(a, vmin(c, d)), vmax(a, vmax(c, d)), i};
         root.refs[i] = r;
         root.geom.grow(r.lo, r.hi);
         root.cent.grow(r.centroid());

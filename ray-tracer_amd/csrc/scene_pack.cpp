@@ -190,11 +190,11 @@ int convert_scene(const rt_bvh_node* nodes, uint32_t n_nodes, const rt_triangle*
 
     // ---- 4-wide tree for occlusion queries (see NodeQuad) ----
     {
-        auto nested = [&](uint32_t child, uint32_t parent) {       // false for NaN bounds
+        auto nested = [&](uint32_t child, uint32_t parent) {       // false for NaN bounds and for boxes stored with min > max
             const rt_bvh_node& c = nodes[child];
             const rt_bvh_node& p = nodes[parent];
             for (int k = 0; k < 3; ++k)
-                if (!(c.min[k] >= p.min[k] && c.max[k] <= p.max[k])) return false;
+                if (!(c.min[k] >= p.min[k] && c.max[k] <= p.max[k] && c.min[k] <= c.max[k])) return false;
             return true;
         };
         // entries of the wide node rooted at binary interior node i
@@ -300,15 +300,21 @@ int convert_scene(const rt_bvh_node* nodes, uint32_t n_nodes, const rt_triangle*
         for (size_t s = 0; s < out.wide.size(); ++s) {
             const NodeQuad& q = out.wide[s];
             NodeCw& w = out.cw[s];
+            // The reference's slab test (intersects.comp:108-118) takes min(t1, t2) and max(t1, t2) per axis, so it does not
+            // care which of a box's two planes is called min: a box stored with min > max on some axis is entered exactly like
+            // the same box with the planes swapped, and is quantised as that box here. A NaN bound is never entered. A bound at
+            // infinity is (a triangle with an infinite coordinate shares its leaf and its ancestors with ordinary ones), but
+            // 8-bit offsets cannot express it: such a scene keeps the exact traversal.
             bool usable[4];
+            float blo[4][3], bhi[4][3];
             for (int k = 0; k < 4; ++k) {
                 usable[k] = q.ref[k] != kRefNone;
-                for (int a = 0; a < 3 && usable[k]; ++a) {     // NaN or inverted bounds are never entered by the reference's slab test
-                    const float lo = q.box[k][a], hi = q.box[k][3 + a];
-                    usable[k] = std::isfinite(lo) && std::isfinite(hi) && lo <= hi;
-                    // ... but a box that reaches to infinity is (a triangle with an infinite coordinate shares its leaf and its
-                    // ancestors with ordinary ones): 8-bit offsets cannot express it, so such a scene keeps the exact traversal
-                    if (!usable[k] && !std::isnan(lo) && !std::isnan(hi) && lo <= hi) out.cw_complete = false;
+                for (int a = 0; a < 3; ++a) {
+                    const float b0 = q.box[k][a], b1 = q.box[k][3 + a];
+                    blo[k][a] = std::fmin(b0, b1); bhi[k][a] = std::fmax(b0, b1);
+                    if (!usable[k]) continue;
+                    if (std::isnan(b0) || std::isnan(b1)) usable[k] = false;
+                    else if (!std::isfinite(b0) || !std::isfinite(b1)) { usable[k] = false; out.cw_complete = false; }
                 }
                 w.ref[k] = usable[k] ? q.ref[k] : kRefNone;
             }
@@ -317,7 +323,7 @@ int convert_scene(const rt_bvh_node* nodes, uint32_t n_nodes, const rt_triangle*
             for (int a = 0; a < 3; ++a) {
                 double lo_min = 1e300, hi_max = -1e300;
                 for (int k = 0; k < 4; ++k)
-                    if (usable[k]) { lo_min = std::min(lo_min, double(q.box[k][a])); hi_max = std::max(hi_max, double(q.box[k][3 + a])); }
+                    if (usable[k]) { lo_min = std::min(lo_min, double(blo[k][a])); hi_max = std::max(hi_max, double(bhi[k][a])); }
                 if (lo_min > hi_max) { lo_min = hi_max = 0.0; }
                 // origin one margin below the lowest box (rounded down to float), step so that the highest box plus a margin
                 // fits into 253 steps (rounded up to float); at least one margin per step
@@ -331,8 +337,8 @@ int convert_scene(const rt_bvh_node* nodes, uint32_t n_nodes, const rt_triangle*
                 for (int k = 0; k < 4; ++k) {
                     uint32_t ql = 255u, qh = 0u;                                   // unused: never entered
                     if (usable[k]) {
-                        long l = long(std::floor((double(q.box[k][a]) - margin - double(p)) / double(st)));
-                        long h = long(std::ceil((double(q.box[k][3 + a]) + margin - double(p)) / double(st)));
+                        long l = long(std::floor((double(blo[k][a]) - margin - double(p)) / double(st)));
+                        long h = long(std::ceil((double(bhi[k][a]) + margin - double(p)) / double(st)));
                         overflow |= h > 255;
                         ql = uint32_t(std::min(255L, std::max(0L, l)));
                         qh = uint32_t(std::min(255L, std::max(0L, h)));

@@ -70,16 +70,19 @@ class HipRenderer:
         self._check(self.lib.rt_upload_textures(self._ctx, texs, len(scene.textures), C.byref(sky) if sky else None))
         cam = np.ascontiguousarray(scene.camera)
         self._check(self.lib.rt_set_camera(self._ctx, ptr(cam)))
+        self._camera_in_use = cam.copy()
         self.scene = scene
 
     # reload_scene (renderer.rs:193-231): the new scene is viewed from where the camera currently is
     # (location and rotation are carried over, renderer.rs:194-196); everything else comes from the new scene.
     def reload_scene(self, scene: Scene):
-        old = getattr(self, "scene", None)
-        if old is not None:
+        import copy
+        current = getattr(self, "_camera_in_use", None)          # what set_camera / set_camera_pose / upload_scene installed last
+        if current is not None:
             cam = np.ascontiguousarray(scene.camera).copy()
-            cam["location"][0] = old.camera["location"][0]
-            cam["rotation"][0] = old.camera["rotation"][0]
+            cam["location"][0] = current["location"][0]
+            cam["rotation"][0] = current["rotation"][0]
+            scene = copy.copy(scene)                              # the caller's Scene keeps its own camera
             scene.camera = cam
         self.upload_scene(scene)
 
@@ -97,10 +100,12 @@ class HipRenderer:
         cam["rotation"][0] = np.asarray(rotation, dtype=np.float32).reshape(16)
         self.scene.camera = cam
         self._check(self.lib.rt_set_camera(self._ctx, ptr(cam)))
+        self._camera_in_use = cam.copy()
 
     def set_camera(self, cam: np.ndarray):
         cam = np.ascontiguousarray(cam)
         self._check(self.lib.rt_set_camera(self._ctx, ptr(cam)))
+        self._camera_in_use = cam.copy()
 
     def reset_accumulator(self):
         self._check(self.lib.rt_reset_accumulation(self._ctx))

@@ -82,6 +82,39 @@ def test_default_traversal_on_degenerate_trees(rt, oracle):
     r.destroy()
 
 
+def test_child_boxes_stored_with_min_above_max(rt, oracle, scene_cache):
+    """A caller-supplied tree may hold a box with min > max on some axis. The reference's slab test (intersects.comp:108-118)
+    takes min(t1, t2) / max(t1, t2) per axis, so it enters such a box exactly like the box with the two planes swapped; the
+    compressed tree has to do the same instead of dropping the child (and every triangle below it)."""
+    import copy
+    sc = copy.deepcopy(scene_cache("atrium", scale=0.05, width=96, height=54))
+    rng = np.random.default_rng(3)
+    nodes = sc.bvh
+    pick = rng.choice(np.arange(1, len(nodes)), size=min(400, len(nodes) - 1), replace=False)      # never the root: it is not box-tested
+    for k, i in enumerate(pick):
+        a = k % 3
+        lo, hi = float(nodes[i]["min"][a]), float(nodes[i]["max"][a])
+        nodes[i]["min"][a], nodes[i]["max"][a] = hi, lo
+    assert (nodes["min"][pick, :3] > nodes["max"][pick, :3]).any(axis=1).mean() > 0.9
+    r = rt.HipRenderer.create(sc, max_bounces=2)
+    x = rt.HipRenderer.create(sc, max_bounces=2, flags=rt.api.RT_EXACT_ORDER)
+    o = oracle.OracleScene(sc)
+    lo = sc.triangles["v"][..., :3].min(axis=(0, 1))
+    hi = sc.triangles["v"][..., :3].max(axis=(0, 1))
+    n = 20000
+    ro, rd = random_rays(rng, n, lo, hi)
+    h, _ = o.trace_closest(ro, rd)
+    assert np.array_equal(x.trace_closest(ro, rd), h)                       # the exact mode is the oracle, bit for bit
+    g = r.trace_closest(ro, rd)
+    ties, recovered = check_hits_up_to_ties(g, h, o, ro, rd, "inverted child boxes")
+    assert ties + recovered <= 0.01 * n
+    assert (g["prim"] != 0xFFFFFFFF).sum() >= (h["prim"] != 0xFFFFFFFF).sum()       # nothing below an inverted box was lost
+    tmax = rng.uniform(0.1, 8.0, size=n).astype(np.float32)
+    assert (r.trace_shadow(ro, rd, tmax) != o.trace_shadow(ro, rd, tmax)).sum() <= 3
+    r.destroy()
+    x.destroy()
+
+
 def test_axis_parallel_and_non_finite_rays(rt, oracle, scene_cache):
     """Direction components of exactly +0 or -0 (an infinite reciprocal) must neither lose hits nor cost more than ordinary
     rays: the compressed boxes are evaluated with fused multiply-adds, where an infinite reciprocal would give inf - inf and

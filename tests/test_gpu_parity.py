@@ -436,12 +436,13 @@ def test_reload_scene_keeps_the_viewer_in_place(rt, scene_cache):
     r = exact_renderer(rt, sc, max_bounces=2)
     moved = sc.camera.copy()
     moved["location"][0][:3] = (0.3, 1.1, 5.0)
-    r.set_camera(moved)
-    r.scene = dataclasses.replace(sc, camera=moved)
+    r.set_camera(moved)                                   # the pose in use is whatever was installed last, by any call
     want_o, want_d, _ = r.generate_rays(0)
-    r.reload_scene(dataclasses.replace(sc))               # the new scene brings the original camera
+    fresh = dataclasses.replace(sc)                       # the new scene brings the original camera
+    r.reload_scene(fresh)
     o, d, _ = r.generate_rays(0)
     assert np.array_equal(o, want_o) and np.array_equal(d, want_d)
+    assert np.array_equal(fresh.camera, sc.camera)        # the caller's scene is left as it was
     assert r.sample_count() == 0
     r.upload_scene(sc)
     o, _, _ = r.generate_rays(0)
