@@ -372,11 +372,12 @@ typedef __attribute__((address_space(3))) uint8_t lds_u8;
 // lane's leaf (P <= 32: 2 columns, else 1), on ray data pulled from the owner with ds_bpermute. The owner then folds
 // its columns in triangle order with the shader's strict "closer" test (intersects.comp:141-150), so the first triangle
 // tested still wins an exact tie. `slot_owner` is this wave's 64-byte LDS strip.
+// `my_leaf` is the leaf reference of a parked lane (`parked`); with `pop_after` the lane continues from its stack afterwards
+// (the leaf was its current node), without it the lane's current node is left alone (the leaf was a postponed one).
 template <bool COUNT, bool ANYHIT>
-RT_DEV void leaf_phase(const SceneDev& sc, LaneRay& r, unsigned long long parked_mask, lds_u8* slot_owner, lds_u32* stack, uint32_t* spill,
-                       uint32_t& n_leaf, uint32_t& n_tri) {
+RT_DEV void leaf_phase(const SceneDev& sc, LaneRay& r, uint32_t my_leaf, bool parked, bool pop_after, unsigned long long parked_mask, lds_u8* slot_owner,
+                       lds_u32* stack, uint32_t* spill, uint32_t& n_leaf, uint32_t& n_tri) {
     const uint32_t lane = lane_id();
-    const bool parked = int32_t(r.cur) < 0;
     const uint32_t P = uint32_t(__popcll(parked_mask));
     const uint32_t rank = uint32_t(__popcll(parked_mask & ((1ull << lane) - 1ull)));
     const uint32_t shift = P <= 16u ? 4u : (P <= 32u ? 5u : 6u);      // wave-uniform
@@ -388,13 +389,13 @@ RT_DEV void leaf_phase(const SceneDev& sc, LaneRay& r, unsigned long long parked
     const uint32_t owner = slot_used ? uint32_t(slot_owner[slot]) : lane;
     const f3 o = {wave_pull(owner, r.o.x), wave_pull(owner, r.o.y), wave_pull(owner, r.o.z)};
     const f3 d = {wave_pull(owner, r.d.x), wave_pull(owner, r.d.y), wave_pull(owner, r.d.z)};
-    const uint32_t leaf = wave_pull(owner, r.cur);
+    const uint32_t leaf = wave_pull(owner, my_leaf);
     const uint32_t first = leaf & 0x01FFFFFFu, count = ((leaf >> 25) & 63u) + 1u;
-    const uint32_t my_first = r.cur & 0x01FFFFFFu;
+    const uint32_t my_first = my_leaf & 0x01FFFFFFu;
 #ifdef RT_OCCUPANCY_PROBE
     if (COUNT && lane == 0) ++n_tri;                     // experiment: leaf phases in the triangle counter
 #else
-    if (COUNT && parked) { ++n_leaf; n_tri += ((r.cur >> 25) & 63u) + 1u; }
+    if (COUNT && parked) { ++n_leaf; n_tri += ((my_leaf >> 25) & 63u) + 1u; }
 #endif
     for (uint32_t base = 0;; base += columns) {
         const bool mine = slot_used && base + col < count;
@@ -416,7 +417,7 @@ RT_DEV void leaf_phase(const SceneDev& sc, LaneRay& r, unsigned long long parked
             r.t = best_t; r.u = bu; r.v = bv; r.prim = my_first + base + best_col;
         }
     }
-    if (parked) {
+    if (parked && pop_after) {
         // ANYHIT: the caller only asks whether anything lies nearer than the initial distance, so a hit ends the ray
         if (ANYHIT && r.prim != kNoPrim) { r.cur = kDone; r.sp = 0; }
         else r.cur = stack_pop(stack, spill, r, false);
@@ -472,6 +473,9 @@ RT_DEV void trace_persistent(const SceneDev& sc, const Work& work, uint32_t n, u
     const uint32_t seg_len = cursor ? (((n - n_static) + kTailCursors * RT_TAIL_CHUNK - 1u) / (kTailCursors * RT_TAIL_CHUNK)) * RT_TAIL_CHUNK : 0u;
     uint32_t seg = wave_id % kTailCursors, segs_empty = 0;
     uint32_t run_lo = 1u, run_hi = 0u, run_base = 0u;                        // wave-uniform: where the items around chunk_pos live (empty at first)
+    // Postponed leaves (closest-hit queries on the compressed tree only; RT_SPECULATE): see phase A
+    constexpr bool SPECULATE = RT_SPECULATE && TREE == kTreeCw && !ANYHIT;
+    uint32_t pend = 0u;
     for (;;) {
         unsigned long long idle = __builtin_amdgcn_ballot_w64(!live);
         uint32_t n_idle = uint32_t(__popcll(idle));
@@ -546,9 +550,16 @@ RT_DEV void trace_persistent(const SceneDev& sc, const Work& work, uint32_t n, u
         }
         // phase A: interior nodes, until enough lanes are parked on a leaf (or no lane has a node left)
         for (;;) {
+            if (SPECULATE) {
+                // a lane that reaches a leaf while it holds no postponed one keeps the leaf for later and goes on with its stack
+                const bool take = int32_t(r.cur) < 0 && pend == 0u;
+                if (__builtin_amdgcn_ballot_w64(take) != 0ull) {
+                    if (take) { pend = r.cur; r.cur = stack_pop(stack, spill, r, false); }
+                }
+            }
             const bool at_node = r.cur < kDone;            // lanes without a ray hold kDone
             if (__builtin_amdgcn_ballot_w64(at_node) == 0ull) break;
-            if (uint32_t(__popcll(__builtin_amdgcn_ballot_w64(int32_t(r.cur) < 0))) >= kLeafBatch) break;
+            if (uint32_t(__popcll(__builtin_amdgcn_ballot_w64(SPECULATE ? pend != 0u : int32_t(r.cur) < 0))) >= kLeafBatch) break;
 #ifdef RT_OCCUPANCY_PROBE
             if (COUNT && lane == 0) ++n_leaf;            // experiment: wave-level node steps in the leaf counter
 #endif
@@ -565,8 +576,14 @@ RT_DEV void trace_persistent(const SceneDev& sc, const Work& work, uint32_t n, u
         // phase B: the parked leaves
         {
             const unsigned long long parked_mask = __builtin_amdgcn_ballot_w64(int32_t(r.cur) < 0);
-            if (RT_COOP_ANYHIT || !ANYHIT) {
-                if (parked_mask != 0ull) leaf_phase<COUNT, ANYHIT>(sc, r, parked_mask, slot_owner, stack, spill, n_leaf, n_tri);
+            if (SPECULATE) {
+                // the postponed leaves of all lanes together; a lane that has run into a second leaf meanwhile keeps it as its
+                // current node and postpones it in turn at the top of the next phase A
+                const unsigned long long pend_mask = __builtin_amdgcn_ballot_w64(pend != 0u);
+                if (pend_mask != 0ull) leaf_phase<COUNT, ANYHIT>(sc, r, pend, pend != 0u, false, pend_mask, slot_owner, stack, spill, n_leaf, n_tri);
+                pend = 0u;
+            } else if (RT_COOP_ANYHIT || !ANYHIT) {
+                if (parked_mask != 0ull) leaf_phase<COUNT, ANYHIT>(sc, r, r.cur, int32_t(r.cur) < 0, true, parked_mask, slot_owner, stack, spill, n_leaf, n_tri);
             } else if (int32_t(r.cur) < 0) {
                 // occlusion queries: each parked lane walks its own leaf and stops at the first hit
                 if (COUNT) ++n_leaf;

@@ -36,6 +36,9 @@ constexpr uint32_t kTraceBlock = RT_TRACE_BLOCK;   // workgroup size of the trav
 #ifndef RT_TAIL_CURSORS
 #define RT_TAIL_CURSORS 1
 #endif
+#ifndef RT_SPECULATE
+#define RT_SPECULATE 0
+#endif
 #ifndef RT_COOP_ANYHIT
 #define RT_COOP_ANYHIT 0
 #endif
