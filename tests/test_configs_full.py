@@ -64,15 +64,18 @@ def test_config0_converged_pair_256spp(rt, oracle, scene_cache, mode):
     r.destroy()
 
 
-GLASS_RMSE_256SPP = 3e-3       # measured 5.5e-4 (mean radiance 1.47)
+GLASS_RMSE_256SPP = {"exact_arith": 3e-3, "default": 8e-3}       # measured 5.5e-4 / 2.5e-3 (mean radiance 1.47)
 
 
-def test_converged_pair_on_a_scene_whose_paths_do_decorrelate(rt, oracle, scene_cache):
+@pytest.mark.parametrize("mode", ["exact_arith", "default"])
+def test_converged_pair_on_a_scene_whose_paths_do_decorrelate(rt, oracle, scene_cache, mode):
     """The Cornell box is diffuse: its paths almost never flip. The glass blob (roughness 0 refraction, 8 bounces) is the
     scene where a last-bit difference in a refracted direction sends a path elsewhere; the converged images still agree,
-    because every such path is a valid sample of the same estimator."""
+    because every such path is a valid sample of the same estimator. With the shade stage's exact arithmetic only sin/cos/
+    log/exp/pow differ from the oracle; with the default (fast) arithmetic every operation may differ in its last bit, more
+    paths part ways, and the 256-sample means differ by the Monte-Carlo noise of those paths."""
     sc = scene_cache("glass_blob", scale=0.05, width=192, height=108)
-    r = rt.HipRenderer.create(sc, max_bounces=8)
+    r = rt.HipRenderer.create(sc, max_bounces=8, flags=rt.api.RT_EXACT_ARITH if mode == "exact_arith" else 0)
     o = oracle.OracleScene(sc)
     spp = 256
     r.render(spp)
@@ -81,8 +84,8 @@ def test_converged_pair_on_a_scene_whose_paths_do_decorrelate(rt, oracle, scene_
     wm = want[..., :3] / want[..., 3:4]
     rmse = float(np.sqrt(np.mean((gm - wm) ** 2)))
     rel = rmse / float(wm.mean())
-    print(f"glass blob 192x108 {spp} spp: RMSE vs oracle {rmse:.2e} (mean radiance {wm.mean():.4f}, relative {rel:.2e})")
-    assert rmse < GLASS_RMSE_256SPP
+    print(f"glass blob 192x108 {spp} spp ({mode}): RMSE vs oracle {rmse:.2e} (mean radiance {wm.mean():.4f}, relative {rel:.2e})")
+    assert rmse < GLASS_RMSE_256SPP[mode]
     assert abs(gm.mean() - wm.mean()) < 5e-3 * wm.mean()
     r.destroy()
 
@@ -98,10 +101,11 @@ CONVERGED = [
 ]
 
 
+@pytest.mark.parametrize("mode", ["exact_arith", "default"])
 @pytest.mark.parametrize("name,kw,rmse_bar,bias_bar", CONVERGED)
-def test_converged_pairs_of_the_other_configurations(rt, oracle, scene_cache, name, kw, rmse_bar, bias_bar):
+def test_converged_pairs_of_the_other_configurations(rt, oracle, scene_cache, name, kw, rmse_bar, bias_bar, mode):
     sc = scene_cache(name, spatial=True, width=192, height=108, **kw)
-    r = rt.HipRenderer.create(sc, max_bounces=8)
+    r = rt.HipRenderer.create(sc, max_bounces=8, flags=rt.api.RT_EXACT_ARITH if mode == "exact_arith" else 0)
     o = oracle.OracleScene(sc)
     spp = 256
     r.render(spp)
@@ -113,7 +117,7 @@ def test_converged_pairs_of_the_other_configurations(rt, oracle, scene_cache, na
     mean = float(wm.mean())
     bias = abs(float(gm.mean()) - mean) / mean
     same = rel_close(gm, wm, 1e-3, 1e-4).all(axis=-1).mean()
-    print(f"{sc.name} 192x108 {spp} spp: RMSE vs oracle {rmse:.2e} (mean radiance {mean:.4f}, relative {rmse / mean:.2e}), "
+    print(f"{sc.name} 192x108 {spp} spp ({mode}): RMSE vs oracle {rmse:.2e} (mean radiance {mean:.4f}, relative {rmse / mean:.2e}), "
           f"mean differs by {bias:.2e}, {same:.4f} of pixels equal to 1e-3")
     assert rmse < rmse_bar * max(mean, 1e-3), (rmse, mean)          # bars are relative to the mean radiance of the image
     assert bias < bias_bar
