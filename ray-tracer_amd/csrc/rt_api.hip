@@ -61,6 +61,7 @@ constexpr uint32_t kDefaultTraceBlocksPerCu = RT_TRACE_WAVES_PER_EU;
 constexpr uint32_t kDefaultShadeBlocksPerCu = 3;
 constexpr float kCheapSlotNs = 1.0f;   // long passes cheaper than this per path (open scenes, tiny scenes) alternate between lanes too:
                                        // measured 0.47-0.78 ns per path on the car, glass and Cornell scenes, 1.2-2.0 on the atrium and the interior
+constexpr uint64_t kOverlapConnectSlots = 12ull << 20;   // passes of up to this many paths (5 frames of 1080p) trace their shadow rays on the side stream
 constexpr uint64_t kSmallPassSlots = 24ull << 20;   // passes of up to this many paths (12 frames of 1080p) alternate between lanes
 
 constexpr uint32_t kMaxLanes = 4;
@@ -390,7 +391,11 @@ int run_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t frames, uint32_t frame
     const uint32_t trace_grid = trace_grid_for(c, n_slots, c->trace_blocks_per_cu);
     const uint32_t shade_grid = grid_for(c, n_slots, c->shade_blocks_per_cu);
     // Shadow rays on the side stream only for passes on the lane's own stream, and never when launches are timed one by one.
-    const bool overlap = c->overlap_connect && st == l.stream && l.side != nullptr && !(c->flags & (RT_KERNEL_TIMING | RT_SINGLE_STREAM));
+    // ... and only for short passes: a launch of a few frames is mostly run-down, which the other grid fills (one 1080p sample per
+    // call: 4.4 instead of 5.1 ms with the host waiting, 3.4 instead of 3.8 ms queued back to back); from about eight frames
+    // on the two grids only take each other's cache lines (2.43 vs 2.47 ms per sample at 8 frames, 2.23 vs 2.27 at 20).
+    const bool overlap = c->overlap_connect && st == l.stream && l.side != nullptr && !(c->flags & (RT_KERNEL_TIMING | RT_SINGLE_STREAM)) &&
+                         uint64_t(n_slots) <= kOverlapConnectSlots;
     bool connect_pending = false;
     for (uint32_t b = 0; b < c->max_bounces; ++b) {
         // this bounce's paths: every slot at bounce 0, afterwards whatever the previous shade appended to its regions
