@@ -77,7 +77,9 @@ typedef struct rt_config {
     uint32_t max_bounces;     /* BOUNCES in main.comp:4 (24 upstream); 0 selects 24                  */
     uint32_t flags;           /* RT_* switches above                                                 */
     uint32_t frames_per_pass; /* samples traced concurrently by one wavefront pass; 0 = automatic.
-                                 Forced to 1 when RT_REF_RGBA8_ACCUM is set.                         */
+                                 Forced to 1 when RT_REF_RGBA8_ACCUM is set. width * height *
+                                 frames_per_pass may not exceed 2^28 - 2^14 path slots
+                                 (RT_ERR_UNSUPPORTED otherwise).                                     */
 } rt_config;
 
 typedef struct rt_ctx rt_ctx;

@@ -321,8 +321,11 @@ int alloc_paths_for(rt_ctx* c, uint32_t fpp_limit) {
     }
     c->fpp = fpp;
     uint64_t slots = uint64_t(fpp) * c->npix;
-    // work distribution adds whole chunk strides to 32-bit item indices: keep them clear of wrap-around
-    if (slots > 0x7FFFFFFFull) return fail(c, RT_ERR_UNSUPPORTED, "resolution x frames_per_pass exceeds 2^31 path slots");
+    // the kernels address the 16-byte path and queue records with 32-bit byte offsets: every queue position (a region of
+    // shard_cap per shard) has to stay below 2^28. (Work distribution adds whole chunk strides to 32-bit item indices,
+    // which this keeps clear of wrap-around as well.)
+    if ((slots + kBlock * kQueueShards) > (1ull << 28))
+        return fail(c, RT_ERR_UNSUPPORTED, "resolution x frames_per_pass exceeds 2^28 path slots (268 M paths per pass)");
     c->slot_cap = uint32_t(slots);
     // append regions: shard k receives at most ceil(ceil(slots/256)/shards) block-iterations of 256 records
     c->shard_cap = uint32_t(((slots + kBlock - 1) / kBlock + kQueueShards - 1) / kQueueShards) * kBlock;

@@ -379,7 +379,7 @@ RT_DEV void leaf_phase(const SceneDev& sc, LaneRay& r, uint32_t my_leaf, bool pa
                        lds_u32* stack, uint32_t* spill, uint32_t& n_leaf, uint32_t& n_tri) {
     const uint32_t lane = lane_id();
     const uint32_t P = uint32_t(__popcll(parked_mask));
-    const uint32_t rank = uint32_t(__popcll(parked_mask & ((1ull << lane) - 1ull)));
+    const uint32_t rank = bits_below_lane(parked_mask);
     const uint32_t shift = P <= 16u ? 4u : (P <= 32u ? 5u : 6u);      // wave-uniform
     const uint32_t columns = 64u >> shift;
     const uint32_t slot = lane & ((1u << shift) - 1u), col = lane >> shift;
@@ -460,7 +460,9 @@ RT_DEV void trace_persistent(const SceneDev& sc, const Work& work, uint32_t n, u
     // through the device-wide cursor in small chunks, so waves that finish their share early take over work from slow
     // ones and the grid runs down together. Without a cursor the whole list is static.
     uint32_t chunk_pos = 0, chunk_end = 0;                                   // wave-uniform
-    const uint32_t wave_id = (blockIdx.x * kTraceBlock + threadIdx.x) >> 6;
+    // readfirstlane: the compiler cannot prove these wave-uniform by itself, and as scalars the whole work-distribution state
+    // (chunk, static share, cursor segment, run cache) stays out of the vector registers the traversal needs
+    const uint32_t wave_id = __builtin_amdgcn_readfirstlane((blockIdx.x * kTraceBlock + threadIdx.x) >> 6);
     uint32_t next_static = wave_id * kChunk;
     const uint32_t static_stride = (gridDim.x * kTraceBlock >> 6) * kChunk;
     const uint32_t n_static = cursor ? ((n - (n >> RT_TAIL_SHIFT)) / kChunk) * kChunk : n;
@@ -492,7 +494,7 @@ RT_DEV void trace_persistent(const SceneDev& sc, const Work& work, uint32_t n, u
                     while (cursor && segs_empty < kTailCursors) {
                         uint32_t off = seg_len;
                         if (lane == 0) off = atomicAdd(cursor + seg * kCounterStride, uint32_t(RT_TAIL_CHUNK));
-                        off = __shfl(off, 0);
+                        off = __builtin_amdgcn_readfirstlane(off);
                         const uint32_t seg_begin = n_static + seg * seg_len;
                         const uint32_t seg_end = seg_begin + seg_len < n ? seg_begin + seg_len : n;
                         if (off < seg_len && seg_begin + off < seg_end) {
@@ -508,8 +510,13 @@ RT_DEV void trace_persistent(const SceneDev& sc, const Work& work, uint32_t n, u
                 }
             }
             uint32_t avail = chunk_end - chunk_pos;
-            uint32_t rank = uint32_t(__popcll(idle & ((1ull << lane) - 1ull)));
-            if (avail != 0u && (chunk_pos < run_lo || chunk_pos >= run_hi)) work.run_of(chunk_pos, run_lo, run_hi, run_base);
+            uint32_t rank = bits_below_lane(idle);
+            if (avail != 0u && (chunk_pos < run_lo || chunk_pos >= run_hi)) {
+                work.run_of(chunk_pos, run_lo, run_hi, run_base);
+                run_lo = __builtin_amdgcn_readfirstlane(run_lo);
+                run_hi = __builtin_amdgcn_readfirstlane(run_hi);
+                run_base = __builtin_amdgcn_readfirstlane(run_base);
+            }
             if (!live && rank < avail) {
                 uint32_t mine = chunk_pos + rank;
                 if (__builtin_expect(mine >= run_hi, 0)) {                   // the chunk runs on into the next region
@@ -691,17 +698,25 @@ __global__ __launch_bounds__(kBlock) void k_raygen(rt_camera cam, PathDev pd, fl
     }                                                                                                             \
     (void)s_prefix;
 
+// Record i of an array of 16-byte records, addressed as scalar base + 32-bit byte offset: the lane keeps one register for
+// the index instead of a zero-extended pair. Valid below 2^28 records (the path-slot limit of a context).
+template <class T>
+RT_DEV T* rec16(T* base, uint32_t i) {
+    static_assert(sizeof(T) == 16, "16-byte records");
+    return reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<T>::type*>(base)) + i * 16u);
+}
+
 struct ExtendWork {
     PathDev pd;
     float4* __restrict__ hit;     // {t, u, v, prim bits} per queue position
     RegionMap map;
     RT_DEV void run_of(uint32_t i, uint32_t& lo, uint32_t& hi, uint32_t& base) const { map.run_of(i, lo, hi, base); }
     RT_DEV void load(uint32_t p, f3& o, f3& d, float& tmax) const {
-        o = xyz(pd.o[p]);
-        d = xyz(pd.d[p]);
+        o = xyz(*rec16(pd.o, p));
+        d = xyz(*rec16(pd.d, p));
         tmax = INFINITY;
     }
-    RT_DEV void store(uint32_t p, const LaneRay& r) const { hit[p] = make_float4(r.t, r.u, r.v, __uint_as_float(r.prim)); }
+    RT_DEV void store(uint32_t p, const LaneRay& r) const { *rec16(hit, p) = make_float4(r.t, r.u, r.v, __uint_as_float(r.prim)); }
 };
 
 // Occluded = a closest hit nearer than tmax whose material is not glass-like (disney.comp:697-701,
@@ -713,20 +728,21 @@ struct ConnectWork {
     RegionMap map;
     RT_DEV void run_of(uint32_t i, uint32_t& lo, uint32_t& hi, uint32_t& base) const { map.run_of(i, lo, hi, base); }
     RT_DEV void load(uint32_t p, f3& o, f3& d, float& tmax) const {
-        float4 o4 = sq.o[p];
+        float4 o4 = *rec16(sq.o, p);
         o = xyz(o4);
-        d = xyz(sq.d[p]);
+        d = xyz(*rec16(sq.d, p));
         tmax = o4.w;
     }
     RT_DEV void store(uint32_t p, const LaneRay& r) const {
         bool blocked = false;
         if (r.prim != kNoPrim) blocked = (__float_as_uint(tri_shade[size_t(r.prim) * 4].w) & 0x80000000u) == 0u;
         if (!blocked) {
-            const uint32_t slot = __float_as_uint(sq.d[p].w);
-            float4 c = sq.c[p];
-            float4 a = rad[slot];
+            const uint32_t slot = __float_as_uint(rec16(sq.d, p)->w);
+            float4 c = *rec16(sq.c, p);
+            float4* ap = rec16(rad, slot);
+            float4 a = *ap;
             a.x += c.x; a.y += c.y; a.z += c.z;
-            rad[slot] = a;
+            *ap = a;
         }
     }
 };
@@ -753,7 +769,7 @@ __global__ __launch_bounds__(kTraceBlock, RT_TRACE_WAVES_PER_EU) void k_extend(S
     const uint32_t n = load_region_prefix(rg, s_prefix);
     uint32_t n_node = 0, n_leaf = 0, n_tri = 0;
     ExtendWork work{pd, hit, RegionMap{(const lds_u32*)s_prefix, rg.cap, rg.counts == nullptr}};
-    trace_persistent<COUNT, false, TREE>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, (lds_u8*)s_owner + (threadIdx.x & ~63u), hot, n_node, n_leaf, n_tri,
+    trace_persistent<COUNT, false, TREE>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, (lds_u8*)s_owner + __builtin_amdgcn_readfirstlane(threadIdx.x & ~63u), hot, n_node, n_leaf, n_tri,
                                          COUNT ? stats->visits[TREE == kTreeBinary ? 0 : 1] : nullptr);
     flush_counts<COUNT>(n_node, n_leaf, n_tri, &stats->extend_node_pops, &stats->extend_leaf_pops, &stats->extend_tri_tests);
 }
@@ -774,7 +790,7 @@ __global__ __launch_bounds__(kTraceBlock, RT_TRACE_WAVES_PER_EU) void k_connect(
     const uint32_t n = load_region_prefix(rg, s_prefix);
     uint32_t n_node = 0, n_leaf = 0, n_tri = 0;
     ConnectWork work{sc.shade, sq, rad, RegionMap{(const lds_u32*)s_prefix, rg.cap, rg.counts == nullptr}};
-    trace_persistent<COUNT, ANYHIT, TREE>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, (lds_u8*)s_owner + (threadIdx.x & ~63u), hot, n_node, n_leaf, n_tri,
+    trace_persistent<COUNT, ANYHIT, TREE>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, (lds_u8*)s_owner + __builtin_amdgcn_readfirstlane(threadIdx.x & ~63u), hot, n_node, n_leaf, n_tri,
                                           COUNT ? stats->visits[TREE == kTreeBinary ? 0 : 1] : nullptr);
     flush_counts<COUNT>(n_node, n_leaf, n_tri, &stats->shadow_node_pops, &stats->shadow_leaf_pops, &stats->shadow_tri_tests);
 }
@@ -922,7 +938,7 @@ __global__ __launch_bounds__(kTraceBlock, RT_TRACE_WAVES_PER_EU) void k_trace_ra
     uint32_t n_node = 0, n_leaf = 0, n_tri = 0;
     RayListWork work{sc.shade, ro, rd, hits, shadow};
     lds_u32* st = (lds_u32*)s_stack + threadIdx.x;
-    lds_u8* ow = (lds_u8*)s_owner + (threadIdx.x & ~63u);
+    lds_u8* ow = (lds_u8*)s_owner + __builtin_amdgcn_readfirstlane(threadIdx.x & ~63u);
     if (any_hit && FAST) trace_persistent<COUNT, true, kTreeCw>(sc, work, n, cursor, st, ow, hot, n_node, n_leaf, n_tri);
     else if (any_hit) trace_persistent<COUNT, true, kTreeWide>(sc, work, n, cursor, st, ow, hot, n_node, n_leaf, n_tri);
     else if (FAST) trace_persistent<COUNT, false, kTreeCw>(sc, work, n, cursor, st, ow, hot, n_node, n_leaf, n_tri);
@@ -952,7 +968,7 @@ __global__ __launch_bounds__(kTraceBlock, RT_TRACE_WAVES_PER_EU) void k_trace_pa
     RT_TRACE_LDS(TREE)
     uint32_t n_node = 0, n_leaf = 0, n_tri = 0;
     PackedRayWork work{o3, d3, hits};
-    trace_persistent<COUNT, false, TREE>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, (lds_u8*)s_owner + (threadIdx.x & ~63u), hot, n_node, n_leaf, n_tri);
+    trace_persistent<COUNT, false, TREE>(sc, work, n, cursor, (lds_u32*)s_stack + threadIdx.x, (lds_u8*)s_owner + __builtin_amdgcn_readfirstlane(threadIdx.x & ~63u), hot, n_node, n_leaf, n_tri);
     flush_counts<COUNT>(n_node, n_leaf, n_tri, &stats->extend_node_pops, &stats->extend_leaf_pops, &stats->extend_tri_tests);
 }
 

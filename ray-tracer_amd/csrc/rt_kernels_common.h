@@ -130,18 +130,20 @@ constexpr uint32_t kVisitSampleMask = 15u;
 
 // ---- wavefront primitives (64 lanes) -------------------------------------------------------------------
 RT_DEV uint32_t lane_id() { return __lane_id(); }
+// Number of set bits of a wavefront mask below the calling lane (v_mbcnt: no per-lane 64-bit mask to keep in registers).
+RT_DEV uint32_t bits_below_lane(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
+}
 
 // Every lane of the wavefront must call this (predicate false for lanes without work).
 // Returns the destination index for lanes with pred == true.
 RT_DEV uint32_t wave_append(bool pred, uint32_t* counter) {
     unsigned long long mask = __ballot(pred);
     uint32_t n = uint32_t(__popcll(mask));
-    uint32_t lane = lane_id();
     uint32_t base = 0;
-    if (n != 0 && lane == 0) base = atomicAdd(counter, n);
+    if (n != 0 && lane_id() == 0) base = atomicAdd(counter, n);
     base = __shfl(base, 0);
-    uint32_t rank = uint32_t(__popcll(mask & ((1ull << lane) - 1ull)));
-    return base + rank;
+    return base + bits_below_lane(mask);
 }
 RT_DEV uint32_t wave_sum(uint32_t v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);

@@ -316,9 +316,9 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_WAVES) void k_shade(SceneDev sc, P
         // queue append: one atomic per wavefront and queue, spread over kQueueShards counters; the records themselves go
         // to the reserved position, so the next bounce reads them as a dense stream
         const uint32_t shard = (base / kBlock) & (kQueueShards - 1u);
-        uint32_t dst = (RT_SHADE_ABLATE & (64 | 2048)) ? uint32_t(__popcll(__ballot(alive) & ((1ull << lane_id()) - 1ull))) : wave_append(alive, sp.next_shard_counts + shard * kCounterStride);
+        uint32_t dst = (RT_SHADE_ABLATE & (64 | 2048)) ? bits_below_lane(__ballot(alive)) : wave_append(alive, sp.next_shard_counts + shard * kCounterStride);
         uint32_t pout_ablate = 0;
-        if (RT_SHADE_ABLATE & 1024) { pout_ablate = base + uint32_t(__popcll(__ballot(alive) & ((1ull << lane_id()) - 1ull))) + (dst == 0xFFFFFFFFu ? 1u : 0u); }
+        if (RT_SHADE_ABLATE & 1024) { pout_ablate = base + bits_below_lane(__ballot(alive)) + (dst == 0xFFFFFFFFu ? 1u : 0u); }
         if (RT_SHADE_ABLATE & 2048) { pout_ablate = shard * sp.shard_cap + (base / (kBlock * kQueueShards)) * kBlock + (threadIdx.x & ~63u) + dst; }
         uint32_t sdst = (RT_SHADE_ABLATE & 32) ? dst : wave_append(want_shadow, sp.shadow_shard_counts + shard * kCounterStride);
         const uint32_t pout = PROBE ? pin : ((RT_SHADE_ABLATE & (1024 | 2048)) ? pout_ablate : (RT_SHADE_ABLATE & 64) ? base + dst : shard * sp.shard_cap + dst);
