@@ -104,6 +104,7 @@ typedef struct rt_counters {
     uint64_t shadow_tri_tests;
     uint64_t extend_leaf_pops;
     uint64_t shadow_leaf_pops;
+    uint64_t tail_paths;        /* paths whose last bounces ran in the per-path kernel (their rays are in the totals above) */
 } rt_counters;
 
 /* What rt_tune_resident_set measured and did. Index 0: the binary tree (walked under RT_EXACT_ORDER); 1: the compressed

@@ -19,7 +19,7 @@ fn main() {
     for s in sources.iter() {
         println!("cargo:rerun-if-changed={}", csrc.join(s).display());
     }
-    for h in ["rt_kernels.h", "rt_kernels_common.h", "rt_shade.h", "rt_device_math.h", "rt_internal.h", "bvh_common.h"].iter() {
+    for h in ["rt_kernels.h", "rt_kernels_common.h", "rt_shade.h", "rt_traverse.h", "rt_device_math.h", "rt_internal.h", "bvh_common.h"].iter() {
         println!("cargo:rerun-if-changed={}", csrc.join(h).display());
     }
     println!("cargo:rerun-if-changed={}", root.join("include").join("rt_api.h").display());

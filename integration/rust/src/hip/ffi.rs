@@ -157,6 +157,7 @@ pub struct RtCounters {
     pub shadow_tri_tests: u64,
     pub extend_leaf_pops: u64,
     pub shadow_leaf_pops: u64,
+    pub tail_paths: u64,
 }
 
 #[repr(C)]

@@ -72,7 +72,7 @@ class RtTimings(C.Structure):
 
 class RtCounters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("camera_rays", "extend_rays", "shadow_rays", "extend_node_pops", "extend_tri_tests",
-                                          "shadow_node_pops", "shadow_tri_tests", "extend_leaf_pops", "shadow_leaf_pops")]
+                                          "shadow_node_pops", "shadow_tri_tests", "extend_leaf_pops", "shadow_leaf_pops", "tail_paths")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

@@ -12,7 +12,7 @@ ROOT = PKG.parent
 CSRC = PKG / "csrc"
 OUT = PKG / "librt_hip.so"
 SOURCES = [CSRC / "rt_api.hip", CSRC / "rt_shade_fast.hip", CSRC / "scene_pack.cpp", CSRC / "bvh_build.cpp", CSRC / "bvh_sbvh.cpp", CSRC / "bvh_sweep.cpp"]
-HEADERS = [CSRC / "bvh_common.h", CSRC / "rt_kernels.h", CSRC / "rt_kernels_common.h", CSRC / "rt_shade.h", CSRC / "rt_device_math.h", CSRC / "rt_internal.h", ROOT / "include" / "rt_api.h",
+HEADERS = [CSRC / "bvh_common.h", CSRC / "rt_kernels.h", CSRC / "rt_kernels_common.h", CSRC / "rt_shade.h", CSRC / "rt_traverse.h", CSRC / "rt_device_math.h", CSRC / "rt_internal.h", ROOT / "include" / "rt_api.h",
            ROOT / "include" / "rt_types.h"]
 # -ffp-contract=off: intersection and shading arithmetic is specified operation by operation (no fused multiply-add),
 # so closest-hit decisions agree bit for bit with a plain IEEE evaluation of the reference shader. rt_shade_fast.hip, the

@@ -64,6 +64,20 @@ constexpr float kCheapSlotNs = 1.0f;   // long passes cheaper than this per path
 constexpr uint64_t kOverlapConnectSlots = 12ull << 20;   // passes of up to this many paths (5 frames of 1080p) trace their shadow rays on the side stream
 constexpr uint64_t kSmallPassSlots = 24ull << 20;   // passes of up to this many paths (12 frames of 1080p) alternate between lanes
 
+// The per-path kernel (k_path_tail) is offered the queue of every bounce from kDefaultTailFrom on, in passes of at most
+// kDefaultTailPassSlots paths, and takes a queue over once it holds at most kDefaultTailMaxPaths paths. Measured, one sample
+// per call queued back to back (tools/one_sample.py): a small pass cannot fill the machine in any bounce, every wavefront
+// launch of it costs the 0.1-0.2 ms its longest ray takes, and the kernel replaces all that are left with one launch
+// (atrium 320x180: 1.08 -> 0.80 ms per sample, car 640x360: 1.06 -> 0.91, interior 480x270: 1.98 -> 1.63, glass blob
+// 640x360: 2.01 -> 1.60, Cornell box 256x256 and 512x512: within 1 %). In a 1080p sample the queues that short come late
+// (118 thousand paths at bounce 5 of the atrium) after bounces that did fill the machine, the kernel is slower than the three
+// bounces of wavefront launches it replaces (3.72 -> 3.83 ms), and merely offering it costs 4 % (the previous bounce's shadow
+// rays have to finish first): hence the limit on the pass size. RT_HIP_TAIL_FROM / RT_HIP_TAIL_MAX / RT_HIP_TAIL_SLOTS
+// override the three numbers (read once per context, at creation; RT_HIP_TAIL_MAX=0 switches the kernel off).
+constexpr uint32_t kDefaultTailFrom = 2;
+constexpr uint32_t kDefaultTailMaxPaths = 128u << 10;
+constexpr uint32_t kDefaultTailPassSlots = 512u << 10;
+
 constexpr uint32_t kMaxLanes = 4;
 
 enum Stage { ST_RAYGEN = 0, ST_EXTEND, ST_SHADE, ST_CONNECT, ST_ACCUM, ST_COUNT };
@@ -97,6 +111,8 @@ struct Lane {
     uint32_t* aux_cursor() const { return counts.as<uint32_t>(); }
     uint32_t* ext_cursor(uint32_t bounce) const { return counts.as<uint32_t>() + size_t(1 + bounce) * kCursorSetWords; }
     uint32_t* con_cursor(uint32_t bounce) const { return counts.as<uint32_t>() + size_t(1 + kMaxBounces + 1 + bounce) * kCursorSetWords; }
+    // the per-path kernel's "workgroups finished" counter of a bounce (the cursor set of the bounce that never exists)
+    uint32_t* tail_done(uint32_t bounce) const { static_assert(kCursorSetWords >= kMaxBounces, "one word per bounce"); return ext_cursor(kMaxBounces) + bounce; }
     // per bounce: kQueueShards append counters for the next bounce's paths, then kQueueShards for the light samples
     uint32_t* shard_counts(uint32_t bounce) const { return counts.as<uint32_t>() + kCountersAt + size_t(bounce) * 2 * kQueueShards * kCounterStride; }
     uint32_t* shadow_counts(uint32_t bounce) const { return shard_counts(bounce) + size_t(kQueueShards) * kCounterStride; }
@@ -155,6 +171,7 @@ struct rt_ctx {
     bool paths_ok = false;                    // path buffers match W x H (false after a resize that ran out of memory)
     int n_cu = 256;
     uint32_t trace_blocks_per_cu = kDefaultTraceBlocksPerCu, shade_blocks_per_cu = kDefaultShadeBlocksPerCu;
+    uint32_t tail_from = kDefaultTailFrom, tail_max_paths = kDefaultTailMaxPaths, tail_pass_slots = kDefaultTailPassSlots;
 
     // scene
     DevBuf nodes, wide, cw, isect, shade, mats, lights, light_tris, cdf, texels, tex_table, sky, srgb;
@@ -400,10 +417,28 @@ int run_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t frames, uint32_t frame
     const bool overlap = c->overlap_connect && st == l.stream && l.side != nullptr && !(c->flags & (RT_KERNEL_TIMING | RT_SINGLE_STREAM)) &&
                          uint64_t(n_slots) <= kOverlapConnectSlots;
     bool connect_pending = false;
+    const bool lds_tables = c->sd.n_mat <= kLdsMats && c->sd.n_emissive <= kLdsLights;
+    // the per-path kernel walks the compressed tree only, keeps no traversal counters and is not timed as a stage
+    const bool offer_tail = c->fast && !count && c->tail_max_paths != 0 && n_slots <= c->tail_pass_slots && !(c->flags & RT_KERNEL_TIMING);
     for (uint32_t b = 0; b < c->max_bounces; ++b) {
         // this bounce's paths: every slot at bounce 0, afterwards whatever the previous shade appended to its regions
         const Regions rin = b == 0 ? Regions{nullptr, c->shard_cap, n_slots} : Regions{l.shard_counts(b - 1), c->shard_cap, 0u};
         const PathDev in = state[b & 1], out = state[(b + 1) & 1];
+        if (offer_tail && b >= c->tail_from) {
+            // its vertices add to the radiance slots the previous bounce's shadow rays still use
+            if (connect_pending) { HIPCHK(c, hipStreamWaitEvent(st, l.connected, 0)); connect_pending = false; }
+            const TailParams tp{b, c->max_bounces, c->flags, l.shard_counts(b - 1), c->shard_cap, c->tail_max_paths, rad, l.tail_done(b), c->tstats()};
+            const uint32_t grid = (c->tail_max_paths + kTailBlock - 1) / kTailBlock;
+            const bool any = c->sd.has_glass == 0;
+            if (!c->exact_arith) rtint::launch_tail_fast(lds_tables, any, grid, st, c->sd, in, tp);
+            else if (lds_tables) {
+                if (any) hipLaunchKernelGGL((k_path_tail<true, true>), dim3(grid), dim3(kTailBlock), 0, st, c->sd, in, tp);
+                else hipLaunchKernelGGL((k_path_tail<true, false>), dim3(grid), dim3(kTailBlock), 0, st, c->sd, in, tp);
+            } else {
+                if (any) hipLaunchKernelGGL((k_path_tail<false, true>), dim3(grid), dim3(kTailBlock), 0, st, c->sd, in, tp);
+                else hipLaunchKernelGGL((k_path_tail<false, false>), dim3(grid), dim3(kTailBlock), 0, st, c->sd, in, tp);
+            }
+        }
         {
             StageTimer tm(c, ST_EXTEND, st);
             // camera rays may start anywhere; every later ray starts on a surface, inside the scene bounds
@@ -416,7 +451,6 @@ int run_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t frames, uint32_t frame
         {
             StageTimer tm(c, ST_SHADE, st);
             ShadeParams sp{b, c->max_bounces, c->flags, rin, hit, out, l.shard_counts(b), sq, l.shadow_counts(b), c->shard_cap, rad, nullptr};
-            const bool lds_tables = c->sd.n_mat <= kLdsMats && c->sd.n_emissive <= kLdsLights;
             if (!c->exact_arith) rtint::launch_shade_fast(lds_tables, false, shade_grid, st, c->sd, in, sp);
             else if (lds_tables) hipLaunchKernelGGL((k_shade<true, false>), dim3(shade_grid), dim3(kBlock), 0, st, c->sd, in, sp);
             else hipLaunchKernelGGL((k_shade<false, false>), dim3(shade_grid), dim3(kBlock), 0, st, c->sd, in, sp);
@@ -513,6 +547,9 @@ extern "C" int rt_create(const rt_config* cfg, rt_ctx** out) {
     if (const char* env = std::getenv("RT_HIP_TRACE_BLOCKS")) c->trace_blocks_per_cu = uint32_t(std::max(1, std::atoi(env)));
     if (const char* env = std::getenv("RT_HIP_SHADE_BLOCKS")) c->shade_blocks_per_cu = uint32_t(std::max(1, std::atoi(env)));
     if (const char* env = std::getenv("RT_HIP_OVERLAP_CONNECT")) c->overlap_connect = std::atoi(env) != 0;
+    if (const char* env = std::getenv("RT_HIP_TAIL_FROM")) c->tail_from = uint32_t(std::max(1, std::atoi(env)));
+    if (const char* env = std::getenv("RT_HIP_TAIL_MAX")) c->tail_max_paths = uint32_t(std::max(0, std::atoi(env)));
+    if (const char* env = std::getenv("RT_HIP_TAIL_SLOTS")) c->tail_pass_slots = uint32_t(std::max(0, std::atoi(env)));
     if (const char* env = std::getenv("RT_HIP_LANES")) {   // tuning aid: 1..4 concurrent passes
         int v = std::atoi(env);
         if (v >= 1 && v <= int(kMaxLanes) && !(c->flags & (RT_SINGLE_STREAM | RT_KERNEL_TIMING | RT_REF_RGBA8_ACCUM))) { c->n_lanes = uint32_t(v); c->second_lane_for_short_passes = false; }
@@ -1077,6 +1114,7 @@ extern "C" int rt_get_counters(rt_ctx* c, rt_counters* out) {
     out->camera_rays = s.camera_rays; out->extend_rays = s.extend_rays; out->shadow_rays = s.shadow_rays;
     out->extend_node_pops = s.extend_node_pops; out->extend_tri_tests = s.extend_tri_tests; out->extend_leaf_pops = s.extend_leaf_pops;
     out->shadow_node_pops = s.shadow_node_pops; out->shadow_tri_tests = s.shadow_tri_tests; out->shadow_leaf_pops = s.shadow_leaf_pops;
+    out->tail_paths = s.tail_paths;
     return RT_OK;
 }
 

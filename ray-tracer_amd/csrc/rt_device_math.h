@@ -8,7 +8,7 @@
 //     summed left to right. Everything but sin/cos/log/exp/pow then equals the CPU evaluation bit for bit.
 //   fast (RT_FAST_ARITH, used by the shade stage unless the caller asks for exact arithmetic): the same formulas with
 //     the hardware's reciprocal, reciprocal square root and square root (1 ulp each) in place of the correctly rounded
-//     operations, FMA contraction, log/exp/pow through the hardware's base-2 instructions and a short-range sine/cosine.
+//     operations, FMA contraction within an expression, log/exp/pow through the hardware's base-2 instructions and a short-range sine/cosine.
 //     Each operation is within 1-2 ulp of the exact one; results stay within 1e-5 relative of the exact mode wherever the
 //     formula itself is well conditioned.
 #pragma once

@@ -121,6 +121,7 @@ struct TraceStats {               // all 64-bit, updated with one atomic per wav
     unsigned long long extend_rays, shadow_rays, camera_rays;
     unsigned long long extend_node_pops, extend_leaf_pops, extend_tri_tests;
     unsigned long long shadow_node_pops, shadow_leaf_pops, shadow_tri_tests;
+    unsigned long long tail_paths;   // paths taken over by the per-path kernel
     // Per-record visit counters (null outside a tuning pass): [0] the binary tree's records, [1] the 4-wide trees' (the
     // compressed tree shares the uncompressed one's record order). Only the counting kernel variants look at them, and
     // only for every 16th work item.

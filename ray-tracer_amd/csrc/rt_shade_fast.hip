@@ -1,7 +1,10 @@
 // The shade stage in the fast arithmetic mode (see rt_device_math.h): the same source as the exact instances in the
 // library's main translation unit, compiled here with hardware reciprocal / square root and FMA contraction.
+// contract(on), not (fast): a product and a sum are fused only where the source writes them in one expression, which the
+// front end decides once for every function; under (fast) the back end fuses across statements as it sees fit in each
+// kernel, and the two kernels that shade vertices (k_shade, k_path_tail) would round a few operations differently.
 #define RT_FAST_ARITH 1
-#pragma clang fp contract(fast)
+#pragma clang fp contract(on)
 
 #include "rt_shade.h"
 
@@ -17,6 +20,19 @@ void launch_shade_fast(bool lds_tables, bool probe, uint32_t grid, hipStream_t s
     } else {
         if (lds_tables) hipLaunchKernelGGL((k_shade<true, false>), g, b, 0, st, sc, pd, sp);
         else hipLaunchKernelGGL((k_shade<false, false>), g, b, 0, st, sc, pd, sp);
+    }
+}
+
+void launch_tail_fast(bool lds_tables, bool anyhit, uint32_t grid, hipStream_t st, const rtdev::SceneDev& sc, const rtdev::PathDev& pd,
+                      const rtdev::TailParams& tp) {
+    using namespace rtdev;
+    const dim3 g(grid), b(kTailBlock);
+    if (lds_tables) {
+        if (anyhit) hipLaunchKernelGGL((k_path_tail<true, true>), g, b, 0, st, sc, pd, tp);
+        else hipLaunchKernelGGL((k_path_tail<true, false>), g, b, 0, st, sc, pd, tp);
+    } else {
+        if (anyhit) hipLaunchKernelGGL((k_path_tail<false, true>), g, b, 0, st, sc, pd, tp);
+        else hipLaunchKernelGGL((k_path_tail<false, false>), g, b, 0, st, sc, pd, tp);
     }
 }
 
