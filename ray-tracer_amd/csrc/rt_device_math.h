@@ -24,6 +24,10 @@
 #define RT_ARITH_NS exact_arith
 #endif
 
+#ifndef RT_SHADE_ABLATE
+#define RT_SHADE_ABLATE 0
+#endif
+
 namespace rtdev {
 
 struct f3 { float x, y, z; };
@@ -408,6 +412,10 @@ RT_DEV f3 disney_sample(const Mat& m, const ShadePoint& sp, float r1, float r2, 
     f3 V = sp.V;
     LobeWeights w = lobe_weights(m, sp.spec_col, fresnel_mix(m, sp.eta, V.z));
     float c0 = w.diffuse, c1 = c0 + w.refl, c2 = c1 + w.refr;
+    // diagnostic builds (see RT_SHADE_ABLATE in rt_shade.h): every vertex samples the diffuse lobe / the reflection lobe, so the
+    // lanes of a wave never part ways here; the difference to the full kernel bounds what sorting vertices by lobe could save
+    if (RT_SHADE_ABLATE & 4096) { c0 = 2.0f; }
+    if (RT_SHADE_ABLATE & 8192) { c0 = -1.0f; c1 = 2.0f; }
     if (lobe_out) *lobe_out = r1 < c0 ? 0 : (r1 < c1 ? 1 : (r1 < c2 ? 2 : 3));
     f3 L;
     if (r1 < c0) {

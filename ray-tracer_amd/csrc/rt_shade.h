@@ -54,7 +54,8 @@ constexpr uint32_t kTailBlock = 256;
 // update, 8 = no stores of the next path state / light sample, 16 = no light sample and no BSDF sample, 32 = a single
 // wave_append, 64 = no atomics (survivors packed at the front of their wave's own input range), 128 = one constant material,
 // 256 = no sky fetch on a miss, 512 = no frame / tint set-up (make_shade_point), 1024 = the atomics are performed but survivors are written
-// as under 64, 2048 = no atomics, survivors written where their region would hold them if every path survived. The pictures such builds produce are wrong.
+// as under 64, 2048 = no atomics, survivors written where their region would hold them if every path survived, 4096 / 8192 = every
+// vertex samples the diffuse / the reflection lobe (rt_device_math.h). The pictures such builds produce are wrong.
 #ifndef RT_SHADE_ABLATE
 #define RT_SHADE_ABLATE 0
 #endif
