@@ -123,6 +123,8 @@ public:
     void upload_textures(const std::vector<rt_texture>& textures, const rt_texture* skybox) {
         check(rt_upload_textures(ctx_, textures.data(), uint32_t(textures.size()), skybox), ctx_);
     }
+    // fp32 cube map of linear radiance, 6 x height x width x rgba, in place of the 8-bit one (no counterpart upstream)
+    void upload_skybox_f32(uint32_t width, uint32_t height, const float* rgba) { check(rt_upload_skybox_f32(ctx_, width, height, rgba), ctx_); }
     // set_camera_pose (renderer.rs:165-168)
     void set_camera(const rt_camera& cam) { check(rt_set_camera(ctx_, &cam), ctx_); camera_in_use_ = cam; have_camera_ = true; }
     void reset_accumulator() { check(rt_reset_accumulation(ctx_), ctx_); }         // renderer.rs:170-177

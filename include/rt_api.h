@@ -248,6 +248,14 @@ int rt_upload_scene(rt_ctx* ctx, const void* blob, const uint64_t sizes[6],
  * (src/scene/mod.rs:49-65). */
 int rt_upload_textures(rt_ctx* ctx, const rt_texture* textures, uint32_t n_textures, const rt_texture* skybox);
 
+/* A cube map of linear radiance in fp32 ("HDR skybox"). No counterpart in the reference, whose cube map is RGBA8 holding
+ * sRGB values like every other image (src/scene/mod.rs:36-65,272-299; src/vulkan/core/image.rs:307-318): an 8-bit sky cannot
+ * hold a sun. rgba: 6 faces in the order +x -x +y -y +z -z, each height x width texels of {r, g, b, a} floats. Sampled exactly
+ * like the 8-bit cube (main.comp:82-84: face by major axis, bilinear, clamped at the face edge) without the sRGB decode; a
+ * sample's luminance is still clamped at 5 before accumulation (main.comp:114-120). Replaces the cube map in use until the
+ * next rt_upload_textures call; resets the accumulation. */
+int rt_upload_skybox_f32(rt_ctx* ctx, uint32_t width, uint32_t height, const float* rgba);
+
 /* Orders the node records by measured use, for the scene and camera now installed. The traversal kernels keep the first
  * records of each tree in LDS; rt_upload_scene fills that prefix by surface area, which ranks nodes by how often a
  * random ray meets them. This call traces one sample per pixel with per-record visit counters (every 16th ray counts),

@@ -320,6 +320,7 @@ extern "C" {
         n_emissive: u32,
     ) -> i32;
     pub fn rt_upload_textures(ctx: *mut RtCtx, textures: *const RtTexture, n_textures: u32, skybox: *const RtTexture) -> i32;
+    pub fn rt_upload_skybox_f32(ctx: *mut RtCtx, width: u32, height: u32, rgba: *const f32) -> i32;
     pub fn rt_tune_resident_set(ctx: *mut RtCtx, report: *mut RtTuneReport) -> i32;
     pub fn rt_set_camera(ctx: *mut RtCtx, cam: *const RtCamera) -> i32;
     pub fn rt_resize(ctx: *mut RtCtx, width: u32, height: u32) -> i32;

@@ -76,6 +76,13 @@ impl HipRenderer {
         check(unsafe { rt_set_camera(self.ctx, &cam as *const _ as *const RtCamera) }, self.ctx)
     }
 
+    /// A cube map of linear fp32 radiance (six faces of height x width x rgba, +x -x +y -y +z -z) in place of the 8-bit one;
+    /// no counterpart in VulkanRenderer, whose sky is an RGBA8 image like every other texture.
+    pub fn upload_skybox_f32(&mut self, width: u32, height: u32, rgba: &[f32]) -> Result<()> {
+        anyhow::ensure!(rgba.len() == (width as usize) * (height as usize) * 24, "skybox needs 6 * width * height * 4 floats");
+        check(unsafe { rt_upload_skybox_f32(self.ctx, width, height, rgba.as_ptr()) }, self.ctx)
+    }
+
     /// reload_scene (renderer.rs:193-231): the viewer stays where it is.
     pub fn reload_scene(&mut self, mut new_scene: Scene) -> Result<()> {
         let old = &self.scene.components.camera;

@@ -93,6 +93,7 @@ struct Scene {
     uint32_t cdf_padded_len = 0;  // length the shader sees through the 16-byte padded binding
     std::vector<Image> textures;
     Image sky;                    // 6 faces, px.size() = 6*w*h*4
+    std::vector<float> sky_f32;   // the build's fp32 cube map (6*w*h*4 floats of linear radiance, sizes in sky.w / sky.h); empty = use `sky`
     float srgb[256];
 };
 
@@ -309,8 +310,12 @@ vec4 sample_cube(const Scene& sc, vec3 d) {
     float fx = x - x0f, fy = y - y0f;
     int x0 = clampi(int(x0f), int(im.w)), x1 = clampi(int(x0f) + 1, int(im.w));
     int y0 = clampi(int(y0f), int(im.h)), y1 = clampi(int(y0f) + 1, int(im.h));
-    const uint8_t* base = &im.px[size_t(face) * im.w * im.h * 4];
-    auto at = [&](int xx, int yy) { return texel(sc, &base[(size_t(yy) * im.w + xx) * 4]); };
+    const uint8_t* base = sc.sky_f32.empty() ? &im.px[size_t(face) * im.w * im.h * 4] : nullptr;
+    const float* fbase = sc.sky_f32.empty() ? nullptr : &sc.sky_f32[size_t(face) * im.w * im.h * 4];
+    auto at = [&](int xx, int yy) {
+        if (fbase) { const float* q = &fbase[(size_t(yy) * im.w + xx) * 4]; return vec4{q[0], q[1], q[2], q[3]}; }    // linear radiance: no decode
+        return texel(sc, &base[(size_t(yy) * im.w + xx) * 4]);
+    };
     vec4 top = lerp4(at(x0, y0), at(x1, y0), fx);
     vec4 bot = lerp4(at(x0, y1), at(x1, y1), fx);
     return lerp4(top, bot, fy);
@@ -930,6 +935,14 @@ void orc_scene_set_textures(void* s, const rt_texture* tex, uint32_t n, const rt
         sc->sky.w = sky->width; sc->sky.h = sky->height;
         sc->sky.px.assign(sky->pixels, sky->pixels + size_t(sky->width) * sky->height * 4 * 6);
     }
+    sc->sky_f32.clear();
+}
+
+// The build's extension (rt_upload_skybox_f32): same addressing and filtering as the 8-bit cube, texels are linear floats.
+void orc_scene_set_skybox_f32(void* s, uint32_t w, uint32_t h, const float* rgba) {
+    Scene* sc = static_cast<Scene*>(s);
+    sc->sky.w = w; sc->sky.h = h;
+    sc->sky_f32.assign(rgba, rgba + size_t(w) * h * 4 * 6);
 }
 
 float orc_pcg(uint32_t* state) { return pcg(*state); }

@@ -93,6 +93,12 @@ class OracleScene:
             self.keep.append(s)
             sky = Tex(s.shape[2], s.shape[1], s.ctypes.data)
         L.orc_scene_set_textures(self.h, texs, C.c_uint32(len(scene.textures)), C.byref(sky) if sky else None)
+        if getattr(scene, "skybox_hdr", None) is not None:
+            f = np.asarray(scene.skybox_hdr, dtype=np.float32)
+            if f.shape[3] == 3:
+                f = np.concatenate([f, np.ones(f.shape[:3] + (1,), np.float32)], axis=-1)
+            f = np.ascontiguousarray(f)
+            L.orc_scene_set_skybox_f32(self.h, C.c_uint32(f.shape[2]), C.c_uint32(f.shape[1]), _p(f))
 
     def __del__(self):
         try:

@@ -117,6 +117,7 @@ API = {
     "rt_destroy": (None, [_P]),
     "rt_upload_scene": (_I, [_P, _P, _P, _U32, _U32, _U32, _U32, _U32]),
     "rt_upload_textures": (_I, [_P, _P, _U32, _P]),
+    "rt_upload_skybox_f32": (_I, [_P, _U32, _U32, _P]),
     "rt_set_camera": (_I, [_P, _P]),
     "rt_resize": (_I, [_P, _U32, _U32]),
     "rt_reset_accumulation": (_I, [_P]),

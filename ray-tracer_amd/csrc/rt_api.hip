@@ -174,7 +174,7 @@ struct rt_ctx {
     uint32_t tail_from = kDefaultTailFrom, tail_max_paths = kDefaultTailMaxPaths, tail_pass_slots = kDefaultTailPassSlots;
 
     // scene
-    DevBuf nodes, wide, cw, isect, shade, mats, lights, light_tris, cdf, texels, tex_table, sky, srgb;
+    DevBuf nodes, wide, cw, isect, shade, mats, lights, light_tris, cdf, texels, tex_table, sky, sky_f32, srgb;
     SceneDev sd{};
     // host copies of the three node arrays, kept for rt_tune_resident_set
     std::vector<rtint::NodePair> h_nodes;
@@ -843,8 +843,30 @@ extern "C" int rt_upload_textures(rt_ctx* c, const rt_texture* textures, uint32_
         tv.sky_w = tv.sky_h = 1;
     }
     tv.sky = c->sky.as<uint32_t>();
+    tv.sky_f32 = nullptr;
+    c->sky_f32.release();
     if (c->sum.p) return clear_accum(c);
     return RT_OK;
+}
+
+
+extern "C" int rt_upload_skybox_f32(rt_ctx* c, uint32_t width, uint32_t height, const float* rgba) {
+    if (!c) return RT_ERR_INVALID;
+    if (!rgba || width == 0 || height == 0) return fail(c, RT_ERR_INVALID, "rt_upload_skybox_f32: empty skybox");
+    if (uint64_t(width) * height * 6 > 0x7FFFFFFFull) return fail(c, RT_ERR_UNSUPPORTED, "rt_upload_skybox_f32: more than 2^31 texels");
+    int rc;
+    if ((rc = bind_device(c)) != RT_OK) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (Lane& l : c->lanes) if (l.stream) HIPCHK(c, hipStreamSynchronize(l.stream));      // passes in flight still read the old cube map
+    const size_t bytes = size_t(width) * height * 6 * sizeof(float4);
+    DevBuf fresh;
+    HIPCHK(c, fresh.ensure(bytes));
+    HIPCHK(c, hipMemcpy(fresh.p, rgba, bytes, hipMemcpyHostToDevice));
+    c->sky_f32.swap(fresh);
+    TexView& tv = c->sd.tex;
+    tv.sky_w = width; tv.sky_h = height;
+    tv.sky_f32 = c->sky_f32.as<float4>();
+    return clear_accum(c);
 }
 
 extern "C" int rt_set_camera(rt_ctx* c, const rt_camera* cam) {

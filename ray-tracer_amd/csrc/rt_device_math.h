@@ -52,6 +52,7 @@ struct TexView {
     uint32_t n_tex;
     const uint32_t* __restrict__ sky;      // 6 faces back to back
     uint32_t sky_w, sky_h;
+    const float4* __restrict__ sky_f32;    // the cube map as linear fp32 radiance (rt_upload_skybox_f32), or null: use `sky`
     const float* __restrict__ srgb;        // 256-entry decode table
 };
 
@@ -206,9 +207,16 @@ RT_DEV f4 sample_cube(const TexView& tv, f3 d, const lds_f32* srgb_lds = nullptr
     float fx = x - x0f, fy = y - y0f;
     int x0 = clampi(int(x0f), W), x1 = clampi(int(x0f) + 1, W);
     int y0 = clampi(int(y0f), H), y1 = clampi(int(y0f) + 1, H);
-    const uint32_t* base = tv.sky + size_t(face) * W * H;
-    f4 t00 = decode_texel(tv, srgb_lds, base[y0 * W + x0]), t10 = decode_texel(tv, srgb_lds, base[y0 * W + x1]);
-    f4 t01 = decode_texel(tv, srgb_lds, base[y1 * W + x0]), t11 = decode_texel(tv, srgb_lds, base[y1 * W + x1]);
+    f4 t00, t10, t01, t11;
+    if (tv.sky_f32) {            // wave-uniform: linear radiance, no decode
+        const float4* base = tv.sky_f32 + size_t(face) * W * H;
+        const float4 a = base[y0 * W + x0], b = base[y0 * W + x1], c = base[y1 * W + x0], e = base[y1 * W + x1];
+        t00 = f4{a.x, a.y, a.z, a.w}; t10 = f4{b.x, b.y, b.z, b.w}; t01 = f4{c.x, c.y, c.z, c.w}; t11 = f4{e.x, e.y, e.z, e.w};
+    } else {
+        const uint32_t* base = tv.sky + size_t(face) * W * H;
+        t00 = decode_texel(tv, srgb_lds, base[y0 * W + x0]); t10 = decode_texel(tv, srgb_lds, base[y0 * W + x1]);
+        t01 = decode_texel(tv, srgb_lds, base[y1 * W + x0]); t11 = decode_texel(tv, srgb_lds, base[y1 * W + x1]);
+    }
     return lerp4(lerp4(t00, t10, fx), lerp4(t01, t11, fx), fy);
 }
 

@@ -4,6 +4,8 @@
 Mirrors `Scene::from_new` / `load_scene_yaml` (src/scene/loader.rs:11-232):
 
     skybox:    [px, nx, py, ny, pz, nz]          six image paths relative to the YAML file (loader.rs:36-46)
+    skybox_hdr: sky.hdr                          (extension, not in the reference) a Radiance RGBE panorama, resampled to an
+                                                 fp32 cube map of skybox_hdr_size (512) texels per edge; replaces `skybox`
     materials: {name: {field: value, ...}}       fields of `Material` (src/types/material.rs:9-29), anything missing keeps
                                                  Material::default(); unknown keys are ignored; colours are integer
                                                  triples divided by 255 (src/types/aligned.rs:44-56)
@@ -166,6 +168,89 @@ def load_cubemap(paths) -> np.ndarray:
     return np.stack(faces)
 
 
+def load_hdr(path) -> np.ndarray:
+    """A Radiance RGBE picture (.hdr, '-Y h +X w' orientation, flat or new-style run-length encoded scanlines) as an
+    (h, w, 3) float32 array of linear radiance. Extension of the build: the reference reads 8-bit images only."""
+    with open(path, "rb") as fh:
+        data = fh.read()
+    if not (data.startswith(b"#?RADIANCE") or data.startswith(b"#?RGBE")):
+        raise SceneFormatError(f"{path}: not a Radiance HDR file")
+    pos = data.find(b"\n\n")
+    if pos < 0:
+        raise SceneFormatError(f"{path}: header not terminated")
+    if b"FORMAT=32-bit_rle_rgbe" not in data[:pos]:
+        raise SceneFormatError(f"{path}: only FORMAT=32-bit_rle_rgbe is supported")
+    end = data.find(b"\n", pos + 2)
+    dims = data[pos + 2:end].split()
+    if len(dims) != 4 or dims[0] != b"-Y" or dims[2] != b"+X":
+        raise SceneFormatError(f"{path}: unsupported orientation {data[pos + 2:end]!r}")
+    h, w = int(dims[1]), int(dims[3])
+    buf = np.frombuffer(data, dtype=np.uint8, offset=end + 1)
+    rgbe = np.empty((h, w, 4), dtype=np.uint8)
+    p = 0
+    for y in range(h):
+        if 8 <= w < 32768 and p + 4 <= len(buf) and buf[p] == 2 and buf[p + 1] == 2 and (int(buf[p + 2]) << 8 | int(buf[p + 3])) == w:
+            p += 4
+            for ch in range(4):                      # each channel of the scanline run-length encoded on its own
+                x = 0
+                while x < w:
+                    n = int(buf[p]); p += 1
+                    if n > 128:
+                        n -= 128
+                        rgbe[y, x:x + n, ch] = buf[p]; p += 1
+                    else:
+                        rgbe[y, x:x + n, ch] = buf[p:p + n]; p += n
+                    x += n
+                if x != w:
+                    raise SceneFormatError(f"{path}: scanline {y} overruns")
+        else:
+            rgbe[y] = buf[p:p + 4 * w].reshape(w, 4); p += 4 * w
+    e = rgbe[..., 3].astype(np.int32)
+    scale = np.where(e == 0, 0.0, np.ldexp(1.0, e - 136)).astype(np.float32)
+    return rgbe[..., :3].astype(np.float32) * scale[..., None]
+
+
+def save_hdr(path, img) -> None:
+    """Writes an (h, w, 3) float array as a flat (not run-length encoded) Radiance RGBE picture."""
+    img = np.asarray(img, dtype=np.float32)
+    m = img.max(axis=-1)
+    mant, ex = np.frexp(m)
+    scale = np.where(m < 1e-32, 0.0, mant * 256.0 / np.maximum(m, 1e-38))
+    rgbe = np.zeros(img.shape[:2] + (4,), dtype=np.uint8)
+    rgbe[..., :3] = np.clip(img * scale[..., None], 0, 255).astype(np.uint8)
+    rgbe[..., 3] = np.where(m < 1e-32, 0, ex + 128).astype(np.uint8)
+    with open(path, "wb") as fh:
+        fh.write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (img.shape[0], img.shape[1]))
+        fh.write(rgbe.tobytes())
+
+
+def equirect_to_cube(img, size: int) -> np.ndarray:
+    """A latitude-longitude panorama (h, w, 3), +Y up, as the (6, size, size, 4) float32 cube map rt_upload_skybox_f32 takes:
+    every cube texel takes the bilinearly filtered panorama value in the direction of its centre, with the face and
+    (s, t) conventions of the cube fetch (main.comp:82-84; +x -x +y -y +z -z)."""
+    img = np.asarray(img, dtype=np.float32)
+    h, w = img.shape[:2]
+    c = (np.arange(size, dtype=np.float64) + 0.5) / size * 2.0 - 1.0
+    sc, tc = np.meshgrid(c, c)                                   # sc along x (columns), tc along y (rows)
+    one = np.ones_like(sc)
+    dirs = [(one, -tc, -sc), (-one, -tc, sc), (sc, one, tc), (sc, -one, -tc), (sc, -tc, one), (-sc, -tc, -one)]
+    out = np.ones((6, size, size, 4), dtype=np.float32)
+    for f, (dx, dy, dz) in enumerate(dirs):
+        n = np.sqrt(dx * dx + dy * dy + dz * dz)
+        lon = np.arctan2(dx, -dz)                                # -z is the centre of the panorama
+        lat = np.arcsin(dy / n)
+        u = (lon / (2 * np.pi) + 0.5) * w - 0.5
+        v = (0.5 - lat / np.pi) * h - 0.5
+        u0, v0 = np.floor(u).astype(int), np.floor(v).astype(int)
+        fu, fv = (u - u0)[..., None], (v - v0)[..., None]
+        x0, x1 = u0 % w, (u0 + 1) % w
+        y0, y1 = np.clip(v0, 0, h - 1), np.clip(v0 + 1, 0, h - 1)
+        top = img[y0, x0, :3] * (1 - fu) + img[y0, x1, :3] * fu
+        bot = img[y1, x0, :3] * (1 - fu) + img[y1, x1, :3] * fu
+        out[f, ..., :3] = top * (1 - fv) + bot * fv
+    return out
+
+
 def load_scene_yaml(path, log=None) -> Scene:
     """The components of a scene file, before the BVH and light table are built (loader.rs:23-232)."""
     path = Path(path)
@@ -180,6 +265,9 @@ def load_scene_yaml(path, log=None) -> Scene:
         if len(doc["skybox"]) != 6:
             raise SceneFormatError("skybox needs exactly six faces")
         skybox = load_cubemap([base / str(p) for p in doc["skybox"]])
+    skybox_hdr = None
+    if isinstance(doc.get("skybox_hdr"), str):            # the build's extension: one Radiance .hdr panorama
+        skybox_hdr = equirect_to_cube(load_hdr(base / doc["skybox_hdr"]), int(doc.get("skybox_hdr_size", 512)))
 
     mats, index_of = [], {}
     if isinstance(doc.get("materials"), dict):
@@ -240,7 +328,7 @@ def load_scene_yaml(path, log=None) -> Scene:
 
     triangles = np.concatenate(tris) if tris else np.zeros(0, dtype=api.TRIANGLE)
     materials = np.concatenate(mats) if mats else np.zeros(0, dtype=api.MATERIAL)
-    return Scene(triangles=triangles, materials=materials, camera=camera, skybox=skybox, name=path.stem)
+    return Scene(triangles=triangles, materials=materials, camera=camera, skybox=skybox, skybox_hdr=skybox_hdr, name=path.stem)
 
 
 def from_new(path, spatial: bool = True, threads: int = 0, log=print) -> Scene:

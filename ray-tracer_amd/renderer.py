@@ -49,6 +49,16 @@ class HipRenderer:
     def _check(self, code):
         return check(code, self._ctx)
 
+    def upload_skybox_hdr(self, faces):
+        """A cube map of linear fp32 radiance, (6, h, w, 4) or (6, h, w, 3), in place of the 8-bit one (no counterpart upstream)."""
+        f = np.asarray(faces, dtype=np.float32)
+        if f.ndim != 4 or f.shape[0] != 6 or f.shape[3] not in (3, 4):
+            raise ValueError("skybox_hdr must have shape (6, h, w, 3 or 4)")
+        if f.shape[3] == 3:
+            f = np.concatenate([f, np.ones(f.shape[:3] + (1,), np.float32)], axis=-1)
+        f = np.ascontiguousarray(f)
+        self._check(self.lib.rt_upload_skybox_f32(self._ctx, f.shape[2], f.shape[1], f.ctypes.data))
+
     # upload_scene (renderer.rs:122-131) / reload_scene (renderer.rs:193-231)
     def upload_scene(self, scene: Scene):
         blob = scene.write_buffers()
@@ -68,6 +78,8 @@ class HipRenderer:
             keep.append(s)
             sky = RtTexture(s.shape[2], s.shape[1], s.ctypes.data)
         self._check(self.lib.rt_upload_textures(self._ctx, texs, len(scene.textures), C.byref(sky) if sky else None))
+        if getattr(scene, "skybox_hdr", None) is not None:
+            self.upload_skybox_hdr(scene.skybox_hdr)
         cam = np.ascontiguousarray(scene.camera)
         self._check(self.lib.rt_set_camera(self._ctx, ptr(cam)))
         self._camera_in_use = cam.copy()

@@ -63,6 +63,7 @@ class Scene:
     lights: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=LIGHT))
     textures: list = field(default_factory=list)   # list of (h, w, 4) uint8 arrays, sRGB-encoded
     skybox: np.ndarray | None = None               # (6, h, w, 4) uint8 or None (white 1x1 cube)
+    skybox_hdr: np.ndarray | None = None           # (6, h, w, 4) float32 linear radiance; used instead of `skybox` when set
     name: str = "scene"
     bvh: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=BVH_NODE))
     emissive_tris: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=EMISSIVE_TRI))

@@ -158,6 +158,18 @@ def _sky_cube(rng, size):
     return faces
 
 
+def _sky_cube_hdr(rng, size, sun=60.0):
+    """The same sky as linear fp32 radiance, with a sun on +Y an 8-bit image cannot hold (peak `sun`)."""
+    ldr = _sky_cube(rng, size)[..., :3].astype(np.float64) / 255.0
+    lin = np.where(ldr <= 0.04045, ldr / 12.92, ((ldr + 0.055) / 1.055) ** 2.4)
+    faces = np.ones((6, size, size, 4), dtype=np.float32)
+    faces[..., :3] = lin
+    t = (np.arange(size) + 0.5) / size
+    yy, xx = np.meshgrid(t, t, indexing="ij")
+    faces[2, ..., :3] += (sun * np.exp(-((xx - 0.6) ** 2 + (yy - 0.4) ** 2) / 0.002))[..., None].astype(np.float32)
+    return faces
+
+
 # ------------------------------------------------------------------------------------------- 1. cornell
 _CORNELL = {  # name: (shape, row-major 3x4 to_world, material) — scenes/cornell-box/scene_v3.xml:66-116
     "Floor": ("rect", [-4.37114e-08, 1, 4.37114e-08, 0, 0, -8.74228e-08, 2, 0, 1, 4.37114e-08, 1.91069e-15, 0], 2),
@@ -332,8 +344,9 @@ def _soup(rng, mesh, n_objects, budget, region_lo, region_hi, mat_ids, res_hint)
         mesh.grid(fn, nu, nv, mat, True, (2, 2))
 
 
-def car(width=1920, height=1080, scale=1.0, tex_size=2048, sky_size=512) -> Scene:
-    """412,845 triangles, 65 materials (clearcoat paint, metal, glass, rubber), one base-colour atlas, sRGB cube map."""
+def car(width=1920, height=1080, scale=1.0, tex_size=2048, sky_size=512, hdr_sky=False) -> Scene:
+    """412,845 triangles, 65 materials (clearcoat paint, metal, glass, rubber), one base-colour atlas, sRGB cube map
+    (`hdr_sky`: additionally the same sky as an fp32 cube map with a sun, which then takes the 8-bit one's place)."""
     rng = _rng(4)
     target = 412_845 if scale >= 1.0 else max(2_000, int(412_845 * scale))
     if scale < 1.0:
@@ -365,8 +378,11 @@ def car(width=1920, height=1080, scale=1.0, tex_size=2048, sky_size=512) -> Scen
     left = max(left, 0)   # reduced-scale variants keep their structural minimum
     mesh.pebbles(rng, left, [-8, 0.01, -8], [8, 0.05, 8], 0.04, [48, 49, 50])
     cam = look_at_camera(width, height, (6.5, 2.4, 6.0), (0.0, 0.8, 0.0), focal_length=1.4, focus_distance=1.0)
-    return Scene(triangles=mesh.triangles(), materials=mats, camera=cam, textures=[_noise_texture(rng, tex_size, (0.6, 0.55, 0.5))],
-                 skybox=_sky_cube(rng, sky_size), name="car-413k" if scale >= 1.0 else f"car-{mesh.count()}")
+    sc = Scene(triangles=mesh.triangles(), materials=mats, camera=cam, textures=[_noise_texture(rng, tex_size, (0.6, 0.55, 0.5))],
+               skybox=_sky_cube(rng, sky_size), name="car-413k" if scale >= 1.0 else f"car-{mesh.count()}")
+    if hdr_sky:
+        sc.skybox_hdr = _sky_cube_hdr(_rng(44), sky_size)
+    return sc
 
 
 def interior(width=3840, height=2160, scale=1.0, tex_size=1024) -> Scene:
