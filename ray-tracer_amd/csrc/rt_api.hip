@@ -78,7 +78,9 @@ constexpr uint32_t kDefaultTailFrom = 2;
 constexpr uint32_t kDefaultTailMaxPaths = 128u << 10;
 constexpr uint32_t kDefaultTailPassSlots = 512u << 10;
 
-constexpr uint32_t kMaxLanes = 4;
+constexpr uint32_t kMaxLanes = 8;
+constexpr uint32_t kDefaultLanes = 4;   // concurrent passes of a context (RT_HIP_LANES overrides)
+constexpr uint32_t kFullLanes = 2;      // lanes sized for passes of any length; the others hold kSmallPassSlots paths
 
 enum Stage { ST_RAYGEN = 0, ST_EXTEND, ST_SHADE, ST_CONNECT, ST_ACCUM, ST_COUNT };
 
@@ -100,6 +102,8 @@ struct Lane {
     bool timed = false;
     uint64_t timed_slots = 0;
     bool busy = false;   // a pass was queued whose radiance the main stream has (or will have) consumed at `consumed`
+    uint32_t shard_cap = 0;   // records per region of this lane's queues
+    uint64_t slot_cap = 0;    // paths a pass on this lane may hold (lanes beyond the second serve short passes only and are smaller)
 
     PathDev state(int k) const { return PathDev{st_o[k].as<float4>(), st_d[k].as<float4>(), st_t[k].as<float4>()}; }
     ShadowDev sq() const { return ShadowDev{sq_o.as<float4>(), sq_d.as<float4>(), sq_c.as<float4>()}; }
@@ -128,6 +132,12 @@ struct Lane {
 constexpr size_t kStaticCursorBytes = size_t(kCursorSetWords) * 4;
 constexpr size_t kStaticBytes = kStaticCursorBytes + size_t(RT_STATIC_MAX_RAYS) * (12 + 12 + 16);
 static __device__ __align__(256) unsigned char scratch[kStaticBytes];
+
+// A context runs up to 2 * lanes + 1 streams at once (9 by default), and HIP multiplexes a process's streams onto
+// GPU_MAX_HW_QUEUES hardware queues, 4 unless the environment says otherwise: streams that share a queue run one after
+// the other, whatever their events say (one 1080p sample per call, four lanes: 3.54 ms with 4 queues, 3.04 with 16). The
+// variable has to be in the environment before the HIP runtime initialises, which happens before any code of this library
+// runs, so the host sets GPU_MAX_HW_QUEUES=16 itself. With the default of 4 everything works; short passes overlap less.
 
 constexpr int kMaxDevices = 64;
 static std::mutex g_static_mutex;
@@ -345,10 +355,14 @@ int alloc_paths_for(rt_ctx* c, uint32_t fpp_limit) {
         return fail(c, RT_ERR_UNSUPPORTED, "resolution x frames_per_pass exceeds 2^28 path slots (268 M paths per pass)");
     c->slot_cap = uint32_t(slots);
     // append regions: shard k receives at most ceil(ceil(slots/256)/shards) block-iterations of 256 records
-    c->shard_cap = uint32_t(((slots + kBlock - 1) / kBlock + kQueueShards - 1) / kQueueShards) * kBlock;
-    const size_t v4 = size_t(c->shard_cap) * kQueueShards * sizeof(float4);      // >= slots records: holds bounce 0 as well
+    auto shard_cap_for = [](uint64_t n) { return uint32_t(((n + kBlock - 1) / kBlock + kQueueShards - 1) / kQueueShards) * kBlock; };
+    c->shard_cap = shard_cap_for(slots);
     for (uint32_t i = 0; i < c->n_lanes; ++i) {
         Lane& l = c->lanes[i];
+        // the first two lanes take passes of any size; the others only ever see short ones (see rt_render)
+        l.slot_cap = i < kFullLanes || !c->second_lane_for_short_passes ? slots : std::min<uint64_t>(slots, kSmallPassSlots);
+        l.shard_cap = shard_cap_for(l.slot_cap);
+        const size_t v4 = size_t(l.shard_cap) * kQueueShards * sizeof(float4);      // >= slot_cap records: holds bounce 0 as well
         for (DevBuf* b : l.path_buffers()) HIPCHK(c, b->ensure(v4));
         HIPCHK(c, l.counts.ensure(sizeof(uint32_t) * Lane::counts_words()));
         HIPCHK(c, hipMemsetAsync(l.counts.p, 0, l.counts.bytes, c->stream));
@@ -396,6 +410,7 @@ void refresh_camera(rt_ctx* c) {
 int run_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t frames, uint32_t frame_first, uint32_t frame_stride, uint32_t* seeds_out) {
     const uint32_t npix = c->npix_pass();
     const uint32_t n_slots = frames * npix;
+    if (uint64_t(n_slots) > l.slot_cap) return fail(c, RT_ERR_DEVICE, "internal: a pass larger than its lane's path buffers");
     const bool count = (c->flags & RT_COUNT_TRAVERSAL) != 0;
     const PathDev state[2] = {l.state(0), l.state(1)};
     ShadowDev sq = l.sq();
@@ -422,12 +437,12 @@ int run_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t frames, uint32_t frame
     const bool offer_tail = c->fast && !count && c->tail_max_paths != 0 && n_slots <= c->tail_pass_slots && !(c->flags & RT_KERNEL_TIMING);
     for (uint32_t b = 0; b < c->max_bounces; ++b) {
         // this bounce's paths: every slot at bounce 0, afterwards whatever the previous shade appended to its regions
-        const Regions rin = b == 0 ? Regions{nullptr, c->shard_cap, n_slots} : Regions{l.shard_counts(b - 1), c->shard_cap, 0u};
+        const Regions rin = b == 0 ? Regions{nullptr, l.shard_cap, n_slots} : Regions{l.shard_counts(b - 1), l.shard_cap, 0u};
         const PathDev in = state[b & 1], out = state[(b + 1) & 1];
         if (offer_tail && b >= c->tail_from) {
             // its vertices add to the radiance slots the previous bounce's shadow rays still use
             if (connect_pending) { HIPCHK(c, hipStreamWaitEvent(st, l.connected, 0)); connect_pending = false; }
-            const TailParams tp{b, c->max_bounces, c->flags, l.shard_counts(b - 1), c->shard_cap, c->tail_max_paths, rad, l.tail_done(b), c->tstats()};
+            const TailParams tp{b, c->max_bounces, c->flags, l.shard_counts(b - 1), l.shard_cap, c->tail_max_paths, rad, l.tail_done(b), c->tstats()};
             const uint32_t grid = (c->tail_max_paths + kTailBlock - 1) / kTailBlock;
             const bool any = c->sd.has_glass == 0;
             if (!c->exact_arith) rtint::launch_tail_fast(lds_tables, any, grid, st, c->sd, in, tp);
@@ -450,7 +465,7 @@ int run_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t frames, uint32_t frame
         if (connect_pending) { HIPCHK(c, hipStreamWaitEvent(st, l.connected, 0)); connect_pending = false; }
         {
             StageTimer tm(c, ST_SHADE, st);
-            ShadeParams sp{b, c->max_bounces, c->flags, rin, hit, out, l.shard_counts(b), sq, l.shadow_counts(b), c->shard_cap, rad, nullptr};
+            ShadeParams sp{b, c->max_bounces, c->flags, rin, hit, out, l.shard_counts(b), sq, l.shadow_counts(b), l.shard_cap, rad, nullptr};
             if (!c->exact_arith) rtint::launch_shade_fast(lds_tables, false, shade_grid, st, c->sd, in, sp);
             else if (lds_tables) hipLaunchKernelGGL((k_shade<true, false>), dim3(shade_grid), dim3(kBlock), 0, st, c->sd, in, sp);
             else hipLaunchKernelGGL((k_shade<false, false>), dim3(shade_grid), dim3(kBlock), 0, st, c->sd, in, sp);
@@ -465,7 +480,7 @@ int run_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t frames, uint32_t frame
             {
                 StageTimer tm(c, ST_CONNECT, cs);
                 const bool any = c->sd.has_glass == 0;
-                const Regions rsh{l.shadow_counts(b), c->shard_cap, 0u};
+                const Regions rsh{l.shadow_counts(b), l.shard_cap, 0u};
                 auto kern = c->fast ? (count ? (any ? k_connect<true, true, true> : k_connect<true, false, true>) : (any ? k_connect<false, true, true> : k_connect<false, false, true>))
                                     : (count ? (any ? k_connect<true, true, false> : k_connect<true, false, false>) : (any ? k_connect<false, true, false> : k_connect<false, false, false>));
                 hipLaunchKernelGGL(kern, dim3(trace_grid), dim3(kTraceBlock), 0, cs, c->sd, sq, rad, rsh, RT_CURSOR(l.con_cursor(b)), c->tstats());
@@ -537,12 +552,15 @@ extern "C" int rt_create(const rt_config* cfg, rt_ctx** out) {
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) c->n_cu = std::max(1, prop.multiProcessorCount);
-    // Two lanes, the second one for short passes only: a pass of more than kSmallPassSlots paths keeps the machine busy
+    // Four lanes, all but the first for short passes only: a pass of more than kSmallPassSlots paths keeps the machine busy
     // on its own, and a second concurrent pass only evicts the first one's tree from L2 / Infinity Cache (4583 vs 4446
     // Mrays/s at 32-frame passes), but short passes (an interactive host renders one sample per call) spend most of
-    // their time running persistent grids down, which the other lane's pass fills (+17 % at one 1080p frame per pass, +6 % at
-    // four, +3.6 % at twelve, -1 % at sixteen). RT_HIP_LANES=1..4 fixes the number of lanes and alternates every pass (bit-identical results either way).
-    c->n_lanes = (c->flags & (RT_SINGLE_STREAM | RT_KERNEL_TIMING | RT_REF_RGBA8_ACCUM)) ? 1 : 2;
+    // their time running persistent grids down, which the other lanes' passes fill. One 1080p sample per call, calls queued
+    // back to back, 1 / 2 / 4 / 8 lanes: atrium 4.8 / 3.4 / 3.0 / 2.8 ms per sample, car 3.2 / 2.2 / 1.6 / 1.45, interior
+    // 7.1 / 5.5 / 4.4 / 4.3 (with the hardware queues below; profiles/r3_lanes_and_hw_queues.txt). Lanes beyond the second are
+    // sized for short passes only (kFullLanes). RT_HIP_LANES=1..8 fixes the number of lanes and alternates every pass
+    // (bit-identical results either way).
+    c->n_lanes = (c->flags & (RT_SINGLE_STREAM | RT_KERNEL_TIMING | RT_REF_RGBA8_ACCUM)) ? 1 : kDefaultLanes;
     c->second_lane_for_short_passes = true;
     if (const char* env = std::getenv("RT_HIP_TRACE_BLOCKS")) c->trace_blocks_per_cu = uint32_t(std::max(1, std::atoi(env)));
     if (const char* env = std::getenv("RT_HIP_SHADE_BLOCKS")) c->shade_blocks_per_cu = uint32_t(std::max(1, std::atoi(env)));
@@ -991,9 +1009,13 @@ extern "C" int rt_render(rt_ctx* c, uint32_t n_samples) {
         uint32_t frames = (left + n_pass - 1) / n_pass;
         --n_pass;
         uint32_t frame_first = c->slice_first + c->local_frame * c->slice_stride;
-        const bool alternate = always_alternate || uint64_t(frames) * npix_pass <= kSmallPassSlots;
-        Lane& l = c->lanes[alternate ? c->next_lane : 0];
-        if (alternate) c->next_lane = (c->next_lane + 1) % c->n_lanes;
+        const bool short_pass = uint64_t(frames) * npix_pass <= kSmallPassSlots;
+        const bool alternate = always_alternate || short_pass;
+        // short passes go round all lanes, long ones (when they alternate at all) only the lanes sized for them
+        const uint32_t pool = short_pass || !c->second_lane_for_short_passes ? c->n_lanes : std::min(c->n_lanes, kFullLanes);
+        const uint32_t lane_index = alternate && c->next_lane < pool ? c->next_lane : 0u;
+        Lane& l = c->lanes[lane_index];
+        if (alternate) c->next_lane = (lane_index + 1) % pool;
         if (l.busy) HIPCHK(c, hipStreamWaitEvent(l.stream, l.consumed, 0));   // its previous radiance has been accumulated
         // time the pass when it has the machine to itself as far as can be known here: the only pass of its call, every
         // other lane idle when it is queued
