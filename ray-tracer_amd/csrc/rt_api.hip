@@ -62,6 +62,7 @@ constexpr uint32_t kDefaultShadeBlocksPerCu = 3;
 constexpr float kCheapSlotNs = 1.0f;   // long passes cheaper than this per path (open scenes, tiny scenes) alternate between lanes too:
                                        // measured 0.47-0.78 ns per path on the car, glass and Cornell scenes, 1.2-2.0 on the atrium and the interior
 constexpr uint64_t kOverlapConnectSlots = 12ull << 20;   // passes of up to this many paths (5 frames of 1080p) trace their shadow rays on the side stream
+constexpr uint32_t kOverlapFromBounce = 8;               // ... and in longer passes from this bounce on, where few paths are left
 constexpr uint64_t kSmallPassSlots = 24ull << 20;   // passes of up to this many paths (12 frames of 1080p) alternate between lanes
 
 // The per-path kernel (k_path_tail) is offered the queue of every bounce from kDefaultTailFrom on, in passes of at most
@@ -429,8 +430,10 @@ int run_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t frames, uint32_t frame
     // ... and only for short passes: a launch of a few frames is mostly run-down, which the other grid fills (one 1080p sample per
     // call: 4.4 instead of 5.1 ms with the host waiting, 3.4 instead of 3.8 ms queued back to back); from about eight frames
     // on the two grids only take each other's cache lines (2.43 vs 2.47 ms per sample at 8 frames, 2.23 vs 2.27 at 20).
-    const bool overlap = c->overlap_connect && st == l.stream && l.side != nullptr && !(c->flags & (RT_KERNEL_TIMING | RT_SINGLE_STREAM)) &&
-                         uint64_t(n_slots) <= kOverlapConnectSlots;
+    // In a long pass the bounces beyond the eighth are sparse whatever the scene (a 24-bounce glass scene: 1.19 -> 1.10 ms per
+    // sample with their shadow rays on the side stream; profiles/r3_all_configs.jsonl).
+    const bool may_overlap = c->overlap_connect && st == l.stream && l.side != nullptr && !(c->flags & (RT_KERNEL_TIMING | RT_SINGLE_STREAM));
+    const bool overlap_all = may_overlap && uint64_t(n_slots) <= kOverlapConnectSlots;
     bool connect_pending = false;
     const bool lds_tables = c->sd.n_mat <= kLdsMats && c->sd.n_emissive <= kLdsLights;
     // the per-path kernel walks the compressed tree only, keeps no traversal counters and is not timed as a stage
@@ -472,6 +475,7 @@ int run_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t frames, uint32_t frame
         }
         if (c->sd.n_light + c->sd.n_emissive != 0) {
             hipStream_t cs = st;
+            const bool overlap = overlap_all || (may_overlap && b >= kOverlapFromBounce);
             if (overlap) {
                 HIPCHK(c, hipEventRecord(l.shaded, st));
                 HIPCHK(c, hipStreamWaitEvent(l.side, l.shaded, 0));
@@ -995,7 +999,9 @@ extern "C" int rt_render(rt_ctx* c, uint32_t n_samples) {
     (void)hipGetLastError();                                     // a pass still running reports "not ready": not an error
     const bool cheap_paths = c->ns_per_slot > 0.0f && c->ns_per_slot < kCheapSlotNs;
     const bool always_alternate = !c->second_lane_for_short_passes || (cheap_paths && c->n_lanes > 1);
-    const uint32_t min_passes = always_alternate ? std::min<uint32_t>(c->n_lanes, n_samples) : 1u;
+    // a long call is cut into one pass per lane that takes long passes (two, unless RT_HIP_LANES fixes the lanes), no more
+    const uint32_t long_pass_lanes = c->second_lane_for_short_passes ? std::min(c->n_lanes, kFullLanes) : c->n_lanes;
+    const uint32_t min_passes = always_alternate ? std::min<uint32_t>(long_pass_lanes, n_samples) : 1u;
     if (c->npix_pass() > c->slot_cap) return fail(c, RT_ERR_UNSUPPORTED, "rt_render: the image is too small for the tile slice that is set");
     // a tile slice has fewer pixels per frame than the path buffers were sized for: more frames fit a pass
     uint32_t fpp = c->fpp;
