@@ -136,7 +136,8 @@ static __device__ __align__(256) unsigned char scratch[kStaticBytes];
 
 // A context runs up to 2 * lanes + 1 streams at once (9 by default), and HIP multiplexes a process's streams onto
 // GPU_MAX_HW_QUEUES hardware queues, 4 unless the environment says otherwise: streams that share a queue run one after
-// the other, whatever their events say (one 1080p sample per call, four lanes: 3.54 ms with 4 queues, 3.04 with 16). The
+// the other, whatever their events say (one 1080p sample per call, four lanes with a side stream each: 3.54 ms with 4 queues, 3.04 with 16; run_pass therefore
+// leaves the side stream alone while other passes are in flight: 3.16 / 3.08 ms). The
 // variable has to be in the environment before the HIP runtime initialises, which happens before any code of this library
 // runs, so the host sets GPU_MAX_HW_QUEUES=16 itself. With the default of 4 everything works; short passes overlap less.
 
@@ -408,7 +409,8 @@ void refresh_camera(rt_ctx* c) {
 }
 
 // One wavefront pass on lane `l`: `frames` samples of every pixel, bounce by bounce. Leaves radiance in l.rad.
-int run_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t frames, uint32_t frame_first, uint32_t frame_stride, uint32_t* seeds_out) {
+int run_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t frames, uint32_t frame_first, uint32_t frame_stride, uint32_t* seeds_out,
+             bool side_stream_ok = true) {
     const uint32_t npix = c->npix_pass();
     const uint32_t n_slots = frames * npix;
     if (uint64_t(n_slots) > l.slot_cap) return fail(c, RT_ERR_DEVICE, "internal: a pass larger than its lane's path buffers");
@@ -432,7 +434,10 @@ int run_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t frames, uint32_t frame
     // on the two grids only take each other's cache lines (2.43 vs 2.47 ms per sample at 8 frames, 2.23 vs 2.27 at 20).
     // In a long pass the bounces beyond the eighth are sparse whatever the scene (a 24-bounce glass scene: 1.19 -> 1.10 ms per
     // sample with their shadow rays on the side stream; profiles/r3_all_configs.jsonl).
-    const bool may_overlap = c->overlap_connect && st == l.stream && l.side != nullptr && !(c->flags & (RT_KERNEL_TIMING | RT_SINGLE_STREAM));
+    // `side_stream_ok`: no other lane has a pass in flight. When one has, that pass fills this one's run-downs already, and a
+    // side stream would only be one more stream on the hardware queues the process has (4 unless the host asked for more:
+    // one 1080p sample per call, back to back, 3.54 ms with side streams and 3.1 ms without).
+    const bool may_overlap = side_stream_ok && c->overlap_connect && st == l.stream && l.side != nullptr && !(c->flags & (RT_KERNEL_TIMING | RT_SINGLE_STREAM));
     const bool overlap_all = may_overlap && uint64_t(n_slots) <= kOverlapConnectSlots;
     bool connect_pending = false;
     const bool lds_tables = c->sd.n_mat <= kLdsMats && c->sd.n_emissive <= kLdsLights;
@@ -1025,12 +1030,13 @@ extern "C" int rt_render(rt_ctx* c, uint32_t n_samples) {
         if (l.busy) HIPCHK(c, hipStreamWaitEvent(l.stream, l.consumed, 0));   // its previous radiance has been accumulated
         // time the pass when it has the machine to itself as far as can be known here: the only pass of its call, every
         // other lane idle when it is queued
-        bool time_it = c->second_lane_for_short_passes && single_pass_call && l.t_begin != nullptr;
-        for (uint32_t i = 0; time_it && i < c->n_lanes; ++i)
-            if (&c->lanes[i] != &l && c->lanes[i].busy && hipEventQuery(c->lanes[i].pass_done) != hipSuccess) time_it = false;
+        bool others_busy = false;
+        for (uint32_t i = 0; !others_busy && i < c->n_lanes; ++i)
+            if (&c->lanes[i] != &l && c->lanes[i].busy && hipEventQuery(c->lanes[i].pass_done) != hipSuccess) others_busy = true;
         (void)hipGetLastError();
+        const bool time_it = c->second_lane_for_short_passes && single_pass_call && l.t_begin != nullptr && !others_busy;
         if (time_it) HIPCHK(c, hipEventRecord(l.t_begin, l.stream));
-        if ((rc = run_pass(c, l, l.stream, frames, frame_first, c->slice_stride, nullptr)) != RT_OK) return rc;
+        if ((rc = run_pass(c, l, l.stream, frames, frame_first, c->slice_stride, nullptr, !others_busy)) != RT_OK) return rc;
         if (time_it) { HIPCHK(c, hipEventRecord(l.t_end, l.stream)); l.timed = true; l.timed_slots = uint64_t(frames) * npix_pass; }
         HIPCHK(c, hipEventRecord(l.pass_done, l.stream));
         HIPCHK(c, hipStreamWaitEvent(c->stream, l.pass_done, 0));
