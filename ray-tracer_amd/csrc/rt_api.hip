@@ -54,11 +54,15 @@ struct DevBuf {
 // device-wide cursor that hands out the tail of each list dynamically.
 #define RT_CURSOR(p) (RT_DYNAMIC ? (p) : nullptr)
 // Grid sizes in 256-thread units per CU. Traversal runs RT_TRACE_WAVES_PER_EU waves per SIMD (the LDS each workgroup
-// needs for stack heads and resident node records sets how many fit); shading is bound by HBM, and two workgroups per
-// CU already saturate it while leaving slots to the other lane's traversal.
+// needs for stack heads and resident node records sets how many fit). Shading: three workgroups per CU are resident at the
+// kernel's 134 VGPRs, but its grid is larger, eight per CU: vertices differ a lot in cost (a miss, a textured hit, a light
+// sample) and a grid-stride loop over exactly the resident workgroups ends when the unluckiest one does, while a grid with
+// workgroups to spare is rebalanced by the dispatcher (per 1080p sample of the atrium: 3/CU 0.366 ms, 4/CU 0.310, 8/CU 0.319,
+// 16/CU 0.306, but 5 or 6/CU 0.37: grids that are a power of two per CU only; four resident waves per SIMD at 127 VGPRs change
+// nothing). Over all configurations 8/CU is 2-8 % of the frame; one sample per call does not care.
 // RT_HIP_TRACE_BLOCKS / RT_HIP_SHADE_BLOCKS override them for tuning runs (read once per context, at creation).
 constexpr uint32_t kDefaultTraceBlocksPerCu = RT_TRACE_WAVES_PER_EU;
-constexpr uint32_t kDefaultShadeBlocksPerCu = 3;
+constexpr uint32_t kDefaultShadeBlocksPerCu = 8;
 constexpr float kCheapSlotNs = 1.0f;   // long passes cheaper than this per path (open scenes, tiny scenes) alternate between lanes too:
                                        // measured 0.47-0.78 ns per path on the car, glass and Cornell scenes, 1.2-2.0 on the atrium and the interior
 constexpr uint64_t kOverlapConnectSlots = 12ull << 20;   // passes of up to this many paths (5 frames of 1080p) trace their shadow rays on the side stream
