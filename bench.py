@@ -82,14 +82,37 @@ def launch_ranks(n):
     return subprocess.run(cmd).returncode
 
 
+def _code_only(text: str) -> str:
+    """C/C++ source without comments and with runs of white space collapsed: what the compiler sees, near enough."""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c == '"' or c == "'":                       # string / character literal: copied whole
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1]); i = j + 1
+        elif text.startswith("//", i):
+            j = text.find("\n", i)
+            i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+            out.append(" ")
+        else:
+            out.append(c); i += 1
+    return " ".join("".join(out).split())
+
+
 def kernel_source_hash():
-    """Hash of everything the device code of librt_hip.so is built from (sources + compiler flags)."""
+    """Hash of everything the device code of librt_hip.so is built from: the code of its sources and headers (comments and
+    layout do not count) and the compiler flags."""
     import hashlib
     from ray_tracer_amd import build as rtbuild
     h = hashlib.sha256()
     for f in sorted(p for p in list(rtbuild.SOURCES) + list(rtbuild.HEADERS) if p.suffix in (".hip", ".h")):
         h.update(f.name.encode())
-        h.update(f.read_bytes())
+        h.update(_code_only(f.read_text()).encode())
     h.update(" ".join(rtbuild.FLAGS).encode())
     return h.hexdigest()[:16]
 

@@ -57,15 +57,16 @@ enum {
                                        square root and no fused multiply-add, so that everything outside sin/cos/log/exp/pow
                                        equals an operation-by-operation IEEE evaluation of the shader bit for bit. Without
                                        it (the default) the same formulas use the hardware reciprocal, reciprocal square
-                                       root and square root (1 ulp each), FMA contraction and base-2 log/exp: about 1.3x
+                                       root and square root (1 ulp each), FMA contraction within an expression and base-2 log/exp: about 1.3x
                                        faster in that kernel, every result within 1e-5 relative of the exact mode wherever
                                        the formula is well conditioned. Implied by RT_EXACT_ORDER. Ray generation,
                                        traversal, triangle tests, texture probes and accumulation are exact in both modes. */
     RT_SINGLE_STREAM     = 1u << 5  /* every kernel of every pass on one stream, one after another. By default the
                                        shadow rays of a bounce run on a side stream beside the next bounce's closest-hit
-                                       search, and short passes (up to 24 Mi paths, 12 frames of 1080p) alternate between
-                                       two sets of path buffers so that consecutive passes overlap; RT_HIP_LANES=1..4
-                                       (environment, read at rt_create) fixes the number of sets for all passes.
+                                       search (while no other pass is in flight), and short passes (up to 24 Mi paths, 12
+                                       frames of 1080p) alternate between four sets of path buffers so that consecutive
+                                       passes overlap; RT_HIP_LANES=1..8 (environment, read at rt_create) fixes the number
+                                       of sets for all passes.
                                        Accumulation order, and therefore every output bit, is the same either way.
                                        Implied by RT_KERNEL_TIMING so that per-kernel times are those of kernels
                                        running alone.                                                            */

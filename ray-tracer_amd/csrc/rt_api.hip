@@ -6,8 +6,8 @@
 // kernels of a render call are queued back to back (no host synchronisation inside rt_render).
 //
 // Stream plan: a wavefront pass runs on a `lane` (a stream, a side stream for its shadow rays, and a private set of
-// path-state buffers). By default there are two lanes and only short passes use the second; with RT_HIP_LANES=n
-// consecutive passes always alternate between n lanes and overlap. Accumulation of every pass is
+// path-state buffers). By default there are four lanes, long passes use the first (or the first two, where paths are cheap)
+// and short passes go round all of them; with RT_HIP_LANES=n consecutive passes always alternate between n lanes and overlap. Accumulation of every pass is
 // queued on the context's main stream in pass order (it waits on the pass's lane through an event, and the lane's next
 // pass waits until its radiance buffer has been consumed), so the floating-point summation order does not depend on how
 // the lanes interleave.
