@@ -378,9 +378,10 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_WAVES) void k_shade(SceneDev sc, P
 
 // The last bounces of a short pass, one path per lane from its current vertex to its end: closest hit, vertex, shadow ray,
 // next closest hit, ... without queues in between. A wavefront launch cannot finish before the longest of its rays has, which
-// takes 0.2 ms however few rays it holds, and a bounce is two such launches; once a pass is down to a few 10^5 paths (one
-// 1080p sample after four or five bounces) those floors are most of its time, while this kernel's critical path is the longest
-// remaining *path*. The kernel looks at the length of the queue of `tp.bounce` and leaves it alone unless it holds between 1
+// takes 0.1-0.2 ms however few rays it holds, and a bounce is two such launches; in a pass too small to fill the machine
+// (a sample of a few 10^5 pixels) those floors are most of the time, while this kernel's critical path is the longest
+// remaining *path*. Its traversal is a plain per-lane loop (no resident records, no regrouping of lanes, 3 waves per SIMD),
+// so it only pays where the alternative is launch floors: the host offers it to small passes only. The kernel looks at the length of the queue of `tp.bounce` and leaves it alone unless it holds between 1
 // and `tp.max_paths` paths; if it takes the queue over, its last workgroup empties the queue's counters, so the wavefront
 // launches that follow in the stream find nothing to do. Every path does exactly what the wavefront kernels would have done
 // with it, in the same order (trace_lane and shade_vertex are the code those kernels run; the adds to a path's radiance slot
