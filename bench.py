@@ -20,9 +20,9 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
-# A render context runs up to nine streams; with HIP's default of 4 hardware queues the ones that share a queue run one
-# after the other. Matters for short passes only (the timed 20-frame passes use one stream at a time), and only takes effect
-# if the HIP runtime has not been initialised yet in this process.
+# With HIP's default of 4 hardware queues the streams of a process that share a queue run one after the other. Matters for
+# short passes only (the timed 20-frame passes use one stream at a time), and only takes effect if the HIP runtime has not
+# been initialised yet in this process.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak

@@ -64,7 +64,7 @@ enum {
     RT_SINGLE_STREAM     = 1u << 5  /* every kernel of every pass on one stream, one after another. By default the
                                        shadow rays of a bounce run on a side stream beside the next bounce's closest-hit
                                        search (while no other pass is in flight), and short passes (up to 24 Mi paths, 12
-                                       frames of 1080p) alternate between four sets of path buffers so that consecutive
+                                       frames of 1080p) alternate between three sets of path buffers so that consecutive
                                        passes overlap; RT_HIP_LANES=1..8 (environment, read at rt_create) fixes the number
                                        of sets for all passes.
                                        Accumulation order, and therefore every output bit, is the same either way.

@@ -160,10 +160,11 @@ def load_library(path: os.PathLike | None = None):
     p = Path(path) if path else LIB_PATH
     if not p.exists():
         raise FileNotFoundError(f"{p} not found: build it first (python -c 'import __graft_entry__ as g; g.build()')")
-    # A context runs up to nine streams at once and HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware
-    # queues (4 by default): streams sharing a queue run one after the other. The variable has to be in the environment
-    # before the HIP runtime initialises; setting it here works when nothing in the process has touched HIP yet. Where
-    # something has (a preloaded library, an earlier import), put GPU_MAX_HW_QUEUES=16 into the process environment instead.
+    # HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default) and streams sharing a queue
+    # run one after the other. A context keeps to four streams by default; with more queues, more lanes pay (RT_HIP_LANES).
+    # The variable has to be in the environment before the HIP runtime initialises; setting it here works when nothing in
+    # the process has touched HIP yet. Where something has (a preloaded library, an earlier import), put
+    # GPU_MAX_HW_QUEUES=16 into the process environment instead.
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     lib = C.CDLL(str(p))
     for name, (res, args) in API.items():

@@ -6,8 +6,8 @@
 // kernels of a render call are queued back to back (no host synchronisation inside rt_render).
 //
 // Stream plan: a wavefront pass runs on a `lane` (a stream, a side stream for its shadow rays, and a private set of
-// path-state buffers). By default there are four lanes, long passes use the first (or the first two, where paths are cheap)
-// and short passes go round all of them; with RT_HIP_LANES=n consecutive passes always alternate between n lanes and overlap. Accumulation of every pass is
+// path-state buffers; as side stream it borrows the next lane's stream). By default there are three lanes, long passes use the
+// first (or the first two, where paths are cheap) and short passes go round all of them; with RT_HIP_LANES=n consecutive passes always alternate between n lanes and overlap. Accumulation of every pass is
 // queued on the context's main stream in pass order (it waits on the pass's lane through an event, and the lane's next
 // pass waits until its radiance buffer has been consumed), so the floating-point summation order does not depend on how
 // the lanes interleave.
@@ -84,7 +84,7 @@ constexpr uint32_t kDefaultTailMaxPaths = 128u << 10;
 constexpr uint32_t kDefaultTailPassSlots = 512u << 10;
 
 constexpr uint32_t kMaxLanes = 8;
-constexpr uint32_t kDefaultLanes = 4;   // concurrent passes of a context (RT_HIP_LANES overrides)
+constexpr uint32_t kDefaultLanes = 3;   // concurrent passes of a context (RT_HIP_LANES overrides): with the main stream, four streams
 constexpr uint32_t kFullLanes = 2;      // lanes sized for passes of any length; the others hold kSmallPassSlots paths
 
 enum Stage { ST_RAYGEN = 0, ST_EXTEND, ST_SHADE, ST_CONNECT, ST_ACCUM, ST_COUNT };
@@ -100,13 +100,26 @@ struct Lane {
     hipEvent_t pass_done = nullptr, consumed = nullptr;
     // connect(b) and extend(b+1) both need only shade(b): the shadow rays of a bounce run on `side` beside the next
     // bounce's closest-hit search, each persistent grid filling the compute units the other leaves as it runs down
-    hipStream_t side = nullptr;
+    hipStream_t side = nullptr;   // the next lane's stream (or, with a single lane, a stream of its own: side_owned)
+    bool side_owned = false;
     hipEvent_t shaded = nullptr, connected = nullptr;
     // device time of the last pass this lane ran with the machine to itself (harvested by the next rt_render call)
     hipEvent_t t_begin = nullptr, t_end = nullptr;
     bool timed = false;
     uint64_t timed_slots = 0;
     bool busy = false;   // a pass was queued whose radiance the main stream has (or will have) consumed at `consumed`
+    // Launch sequences of short passes on this lane, captured once and replayed (see queue_pass)
+    struct PassGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; hipGraphNode_t raygen = nullptr;
+                       uint64_t epoch = 0; uint32_t frames = 0; bool side_ok = false; };
+    PassGraph graphs[4];
+    uint32_t next_graph = 0;
+    void drop_graphs() {
+        for (PassGraph& g : graphs) {
+            if (g.exec) (void)hipGraphExecDestroy(g.exec);
+            if (g.graph) (void)hipGraphDestroy(g.graph);
+            g = PassGraph{};
+        }
+    }
     uint32_t shard_cap = 0;   // records per region of this lane's queues
     uint64_t slot_cap = 0;    // paths a pass on this lane may hold (lanes beyond the second serve short passes only and are smaller)
 
@@ -138,12 +151,11 @@ constexpr size_t kStaticCursorBytes = size_t(kCursorSetWords) * 4;
 constexpr size_t kStaticBytes = kStaticCursorBytes + size_t(RT_STATIC_MAX_RAYS) * (12 + 12 + 16);
 static __device__ __align__(256) unsigned char scratch[kStaticBytes];
 
-// A context runs up to 2 * lanes + 1 streams at once (9 by default), and HIP multiplexes a process's streams onto
-// GPU_MAX_HW_QUEUES hardware queues, 4 unless the environment says otherwise: streams that share a queue run one after
-// the other, whatever their events say (one 1080p sample per call, four lanes with a side stream each: 3.54 ms with 4 queues, 3.04 with 16; run_pass therefore
-// leaves the side stream alone while other passes are in flight: 3.16 / 3.08 ms). The
-// variable has to be in the environment before the HIP runtime initialises, which happens before any code of this library
-// runs, so the host sets GPU_MAX_HW_QUEUES=16 itself. With the default of 4 everything works; short passes overlap less.
+// HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues, 4 unless the environment says otherwise, and
+// streams that share a queue run one after the other whatever their events say. A context therefore runs four streams by
+// default (three lanes and the main stream; a lane borrows its neighbour's stream as its side stream while the neighbour is
+// idle). A host that sets GPU_MAX_HW_QUEUES=16 before the HIP runtime initialises (which happens before any code of this
+// library runs) can afford more lanes (RT_HIP_LANES): 8 lanes and 32 queues bring one 1080p sample per call to 2.8 ms.
 
 constexpr int kMaxDevices = 64;
 static std::mutex g_static_mutex;
@@ -188,6 +200,8 @@ struct rt_ctx {
     int n_cu = 256;
     uint32_t trace_blocks_per_cu = kDefaultTraceBlocksPerCu, shade_blocks_per_cu = kDefaultShadeBlocksPerCu;
     uint32_t tail_from = kDefaultTailFrom, tail_max_paths = kDefaultTailMaxPaths, tail_pass_slots = kDefaultTailPassSlots;
+    bool use_graphs = false;                  // short passes are replayed from captured HIP graphs (RT_HIP_GRAPH)
+    uint64_t graph_epoch = 1;                 // bumped by every entry point that may change what a pass's kernels are given
 
     // scene
     DevBuf nodes, wide, cw, isect, shade, mats, lights, light_tris, cdf, texels, tex_table, sky, sky_f32, srgb;
@@ -266,7 +280,15 @@ uint32_t trace_grid_for(const rt_ctx* c, uint64_t n, uint32_t blocks_per_cu) {
 
 // Every entry point that touches the device comes through here; all of them except rt_render may queue work on the main
 // stream that the next pass has to see (clears, uploads, stage-level calls on lane 0's buffers).
-int bind_device(rt_ctx* c) { HIPCHK(c, hipSetDevice(c->device)); c->lanes_must_wait = true; return RT_OK; }
+int bind_device(rt_ctx* c) { HIPCHK(c, hipSetDevice(c->device)); c->lanes_must_wait = true; ++c->graph_epoch; return RT_OK; }
+// For entry points that leave scene, camera, sizes and slices alone (rendering, waiting, reading results): captured pass
+// graphs stay valid.
+int bind_device_keep_graphs(rt_ctx* c) {
+    const uint64_t epoch = c->graph_epoch;
+    const int rc = bind_device(c);
+    c->graph_epoch = epoch;
+    return rc;
+}
 
 hipEvent_t take_event(rt_ctx* c) {
     if (c->events_used == c->event_pool.size()) {
@@ -438,9 +460,8 @@ int run_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t frames, uint32_t frame
     // on the two grids only take each other's cache lines (2.43 vs 2.47 ms per sample at 8 frames, 2.23 vs 2.27 at 20).
     // In a long pass the bounces beyond the eighth are sparse whatever the scene (a 24-bounce glass scene: 1.19 -> 1.10 ms per
     // sample with their shadow rays on the side stream; profiles/r3_all_configs.jsonl).
-    // `side_stream_ok`: no other lane has a pass in flight. When one has, that pass fills this one's run-downs already, and a
-    // side stream would only be one more stream on the hardware queues the process has (4 unless the host asked for more:
-    // one 1080p sample per call, back to back, 3.54 ms with side streams and 3.1 ms without).
+    // `side_stream_ok`: no other lane has a pass in flight. When one has, that pass fills this one's run-downs already, and the
+    // side stream, which is the next lane's stream, is not free.
     const bool may_overlap = side_stream_ok && c->overlap_connect && st == l.stream && l.side != nullptr && !(c->flags & (RT_KERNEL_TIMING | RT_SINGLE_STREAM));
     const bool overlap_all = may_overlap && uint64_t(n_slots) <= kOverlapConnectSlots;
     bool connect_pending = false;
@@ -513,6 +534,75 @@ int finish_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t n_slots) {
     return RT_OK;
 }
 
+// Queues one pass on its lane's stream: directly, or, for short passes, as a HIP graph captured from the first such pass and
+// replayed afterwards. A one-sample pass is 26 kernel launches, two dozen event operations and a memset, 0.38 ms of host time
+// and 4-26 % of the device time between kernels; replayed, it is one launch. Everything a pass's kernels are given is fixed
+// while scene, camera, sizes and slices stay as they are (graph_epoch) except the first frame index, a kernel argument of the
+// ray-generation node that is updated before every replay.
+constexpr uint64_t kGraphPassSlots = kOverlapConnectSlots;
+int queue_pass(rt_ctx* c, Lane& l, uint32_t frames, uint32_t frame_first, bool side_ok) {
+    const uint32_t npix = c->npix_pass();
+    const uint64_t n_slots = uint64_t(frames) * npix;
+    if (!c->use_graphs || n_slots == 0 || n_slots > kGraphPassSlots || (c->flags & (RT_KERNEL_TIMING | RT_COUNT_TRAVERSAL | RT_SINGLE_STREAM)))
+        return run_pass(c, l, l.stream, frames, frame_first, c->slice_stride, nullptr, side_ok);
+    Lane::PassGraph* g = nullptr;
+    for (Lane::PassGraph& k : l.graphs)
+        if (k.exec && k.epoch == c->graph_epoch && k.frames == frames && k.side_ok == side_ok) g = &k;
+    if (!g) {
+        g = &l.graphs[l.next_graph];
+        l.next_graph = (l.next_graph + 1) % (sizeof(l.graphs) / sizeof(l.graphs[0]));
+        if (g->exec) (void)hipGraphExecDestroy(g->exec);
+        if (g->graph) (void)hipGraphDestroy(g->graph);
+        *g = Lane::PassGraph{};
+        HIPCHK(c, hipStreamBeginCapture(l.stream, hipStreamCaptureModeThreadLocal));
+        const int rc = run_pass(c, l, l.stream, frames, frame_first, c->slice_stride, nullptr, side_ok);
+        hipGraph_t graph = nullptr;
+        const hipError_t e = hipStreamEndCapture(l.stream, &graph);
+        if (rc != RT_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        HIPCHK(c, e);
+        size_t n_nodes = 0;
+        HIPCHK(c, hipGraphGetNodes(graph, nullptr, &n_nodes));
+        std::vector<hipGraphNode_t> nodes(n_nodes);
+        HIPCHK(c, hipGraphGetNodes(graph, nodes.data(), &n_nodes));
+        hipGraphNode_t raygen = nullptr;
+        for (hipGraphNode_t nd : nodes) {
+            hipGraphNodeType ty;
+            if (hipGraphNodeGetType(nd, &ty) != hipSuccess || ty != hipGraphNodeTypeKernel) continue;
+            hipKernelNodeParams kp{};
+            if (hipGraphKernelNodeGetParams(nd, &kp) == hipSuccess && kp.func == reinterpret_cast<void*>(k_raygen)) raygen = nd;
+        }
+        hipGraphExec_t exec = nullptr;
+        const hipError_t ie = raygen ? hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) : hipErrorInvalidValue;
+        if (ie != hipSuccess) {
+            // no graph for this pass: queue it the ordinary way and stop trying
+            (void)hipGraphDestroy(graph);
+            (void)hipGetLastError();
+            c->use_graphs = false;
+            return run_pass(c, l, l.stream, frames, frame_first, c->slice_stride, nullptr, side_ok);
+        }
+        g->graph = graph; g->exec = exec; g->raygen = raygen; g->epoch = c->graph_epoch; g->frames = frames; g->side_ok = side_ok;
+    } else {
+        // the same arguments run_pass gave the node, with this pass's first frame index
+        rt_camera cam = c->cam;
+        PathDev pd = l.state(0);
+        float4* rad = l.rad.as<float4>();
+        uint32_t a_npix = npix, a_slots = uint32_t(n_slots), a_first = frame_first, a_stride = c->slice_stride;
+        uint32_t* seeds_out = nullptr;
+        TileSlice tiles = c->tiles();
+        void* args[] = {&cam, &pd, &rad, &a_npix, &a_slots, &a_first, &a_stride, &seeds_out, &tiles};
+        hipKernelNodeParams kp{};
+        kp.func = reinterpret_cast<void*>(k_raygen);
+        kp.gridDim = dim3(grid_for(c, n_slots, 8));
+        kp.blockDim = dim3(kBlock);
+        kp.sharedMemBytes = 0;
+        kp.kernelParams = args;
+        kp.extra = nullptr;
+        HIPCHK(c, hipGraphExecKernelNodeSetParams(g->exec, g->raygen, &kp));
+    }
+    HIPCHK(c, hipGraphLaunch(g->exec, l.stream));
+    return RT_OK;
+}
+
 int ready_to_render(rt_ctx* c) {
     if (!c->have_scene) return fail(c, RT_ERR_NO_SCENE, "no scene uploaded");
     if (!c->have_camera) return fail(c, RT_ERR_NO_SCENE, "no camera set");
@@ -565,14 +655,16 @@ extern "C" int rt_create(const rt_config* cfg, rt_ctx** out) {
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) c->n_cu = std::max(1, prop.multiProcessorCount);
-    // Four lanes, all but the first for short passes only: a pass of more than kSmallPassSlots paths keeps the machine busy
+    // Three lanes, all but the first for short passes only: a pass of more than kSmallPassSlots paths keeps the machine busy
     // on its own, and a second concurrent pass only evicts the first one's tree from L2 / Infinity Cache (4583 vs 4446
     // Mrays/s at 32-frame passes), but short passes (an interactive host renders one sample per call) spend most of
-    // their time running persistent grids down, which the other lanes' passes fill. One 1080p sample per call, calls queued
-    // back to back, 1 / 2 / 4 / 8 lanes: atrium 4.8 / 3.4 / 3.0 / 2.8 ms per sample, car 3.2 / 2.2 / 1.6 / 1.45, interior
-    // 7.1 / 5.5 / 4.4 / 4.3 (with the hardware queues below; profiles/r3_lanes_and_hw_queues.txt). Lanes beyond the second are
-    // sized for short passes only (kFullLanes). RT_HIP_LANES=1..8 fixes the number of lanes and alternates every pass
-    // (bit-identical results either way).
+    // their time running persistent grids down, which the other lanes' passes fill. Three, because with the main stream
+    // that makes four streams, one per hardware queue HIP gives a process by default: streams that share a queue run one
+    // after the other whatever their events say, and which streams share is up to the runtime (with four lanes and a side
+    // stream each, one 1080p sample per call took 3.16 or 3.77 ms depending on what the process had created before; with
+    // four streams it takes 3.2 ms either way, and the host that waits for every sample gets 4.33 instead of 4.5 ms).
+    // profiles/r3_lanes_and_hw_queues.txt. The third lane is sized for short passes only (kFullLanes). RT_HIP_LANES=1..8
+    // fixes the number of lanes and alternates every pass (bit-identical results either way).
     c->n_lanes = (c->flags & (RT_SINGLE_STREAM | RT_KERNEL_TIMING | RT_REF_RGBA8_ACCUM)) ? 1 : kDefaultLanes;
     c->second_lane_for_short_passes = true;
     if (const char* env = std::getenv("RT_HIP_TRACE_BLOCKS")) c->trace_blocks_per_cu = uint32_t(std::max(1, std::atoi(env)));
@@ -581,6 +673,7 @@ extern "C" int rt_create(const rt_config* cfg, rt_ctx** out) {
     if (const char* env = std::getenv("RT_HIP_TAIL_FROM")) c->tail_from = uint32_t(std::max(1, std::atoi(env)));
     if (const char* env = std::getenv("RT_HIP_TAIL_MAX")) c->tail_max_paths = uint32_t(std::max(0, std::atoi(env)));
     if (const char* env = std::getenv("RT_HIP_TAIL_SLOTS")) c->tail_pass_slots = uint32_t(std::max(0, std::atoi(env)));
+    if (const char* env = std::getenv("RT_HIP_GRAPH")) c->use_graphs = std::atoi(env) != 0;
     if (const char* env = std::getenv("RT_HIP_LANES")) {   // tuning aid: 1..4 concurrent passes
         int v = std::atoi(env);
         if (v >= 1 && v <= int(kMaxLanes) && !(c->flags & (RT_SINGLE_STREAM | RT_KERNEL_TIMING | RT_REF_RGBA8_ACCUM))) { c->n_lanes = uint32_t(v); c->second_lane_for_short_passes = false; }
@@ -603,14 +696,22 @@ extern "C" int rt_create(const rt_config* cfg, rt_ctx** out) {
     // Every stream of a confined context carries the mask, the main stream (accumulate, clears, copies) included: a process
     // whose context launched on masked and on ordinary streams side by side did not return from the HIP runtime's exit
     // handler, one whose streams are all masked does.
-    if ((masked ? hipExtStreamCreateWithCUMask(&c->stream, 8, cu_mask) : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
-        c->err = "hipStreamCreate failed"; return bail(RT_ERR_DEVICE);
+    {
+        // lanes + main = four streams by default, one per hardware queue HIP gives a process unless told otherwise; a lane has no
+        // side stream of its own but borrows the next lane's stream, which is idle whenever a side stream is used at all
+        auto make = [&](hipStream_t* st) { return masked ? hipExtStreamCreateWithCUMask(st, 8, cu_mask) : hipStreamCreateWithFlags(st, hipStreamNonBlocking); };
+        for (uint32_t i = 0; i < c->n_lanes; ++i)
+            if (make(&c->lanes[i].stream) != hipSuccess) { c->err = "hipStreamCreate failed"; return bail(RT_ERR_DEVICE); }
+        if (make(&c->stream) != hipSuccess) { c->err = "hipStreamCreate failed"; return bail(RT_ERR_DEVICE); }
+        if (c->n_lanes == 1 && !(c->flags & (RT_SINGLE_STREAM | RT_KERNEL_TIMING))) {
+            if (make(&c->lanes[0].side) != hipSuccess) { c->err = "hipStreamCreate failed"; return bail(RT_ERR_DEVICE); }
+            c->lanes[0].side_owned = true;
+        }
+        for (uint32_t i = 0; c->n_lanes > 1 && i < c->n_lanes; ++i) c->lanes[i].side = c->lanes[(i + 1) % c->n_lanes].stream;
     }
     for (uint32_t i = 0; i < c->n_lanes; ++i) {
         Lane& l = c->lanes[i];
-        hipError_t se = masked ? hipExtStreamCreateWithCUMask(&l.stream, 8, cu_mask) : hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking);
-        if (se == hipSuccess) se = masked ? hipExtStreamCreateWithCUMask(&l.side, 8, cu_mask) : hipStreamCreateWithFlags(&l.side, hipStreamNonBlocking);
-        if (se == hipSuccess) se = hipEventCreateWithFlags(&l.shaded, hipEventDisableTiming);
+        hipError_t se = hipEventCreateWithFlags(&l.shaded, hipEventDisableTiming);
         if (se == hipSuccess) se = hipEventCreateWithFlags(&l.connected, hipEventDisableTiming);
         if (se == hipSuccess) se = hipEventCreate(&l.t_begin);
         if (se == hipSuccess) se = hipEventCreate(&l.t_end);
@@ -643,13 +744,14 @@ extern "C" void rt_destroy(rt_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     for (Lane& l : c->lanes) {
+        l.drop_graphs();
         if (l.pass_done) (void)hipEventDestroy(l.pass_done);
         if (l.consumed) (void)hipEventDestroy(l.consumed);
         if (l.t_begin) (void)hipEventDestroy(l.t_begin);
         if (l.t_end) (void)hipEventDestroy(l.t_end);
         if (l.shaded) (void)hipEventDestroy(l.shaded);
         if (l.connected) (void)hipEventDestroy(l.connected);
-        if (l.side) (void)hipStreamDestroy(l.side);
+        if (l.side && l.side_owned) (void)hipStreamDestroy(l.side);
         if (l.stream) (void)hipStreamDestroy(l.stream);
     }
     if (c->call_mark) (void)hipEventDestroy(c->call_mark);
@@ -945,7 +1047,7 @@ extern "C" int rt_resize(rt_ctx* c, uint32_t w, uint32_t h) {
 extern "C" int rt_reset_accumulation(rt_ctx* c) {
     if (!c) return RT_ERR_INVALID;
     int rc;
-    if ((rc = bind_device(c)) != RT_OK) return rc;
+    if ((rc = bind_device_keep_graphs(c)) != RT_OK) return rc;
     return clear_accum(c);
 }
 
@@ -979,7 +1081,7 @@ extern "C" int rt_render(rt_ctx* c, uint32_t n_samples) {
     int rc;
     if ((rc = ready_to_render(c)) != RT_OK) return rc;
     const bool must_wait = c->lanes_must_wait;
-    if ((rc = bind_device(c)) != RT_OK) return rc;
+    if ((rc = bind_device_keep_graphs(c)) != RT_OK) return rc;
     begin_call(c);
     // Whatever other entry points queued on the main stream (clears, uploads, stage-level calls) precedes this call's passes.
     // Between two rt_render calls with nothing in between there is no such work, and waiting for the main stream would
@@ -1040,7 +1142,7 @@ extern "C" int rt_render(rt_ctx* c, uint32_t n_samples) {
         (void)hipGetLastError();
         const bool time_it = c->second_lane_for_short_passes && single_pass_call && l.t_begin != nullptr && !others_busy;
         if (time_it) HIPCHK(c, hipEventRecord(l.t_begin, l.stream));
-        if ((rc = run_pass(c, l, l.stream, frames, frame_first, c->slice_stride, nullptr, !others_busy)) != RT_OK) return rc;
+        if ((rc = queue_pass(c, l, frames, frame_first, !others_busy)) != RT_OK) return rc;
         if (time_it) { HIPCHK(c, hipEventRecord(l.t_end, l.stream)); l.timed = true; l.timed_slots = uint64_t(frames) * npix_pass; }
         HIPCHK(c, hipEventRecord(l.pass_done, l.stream));
         HIPCHK(c, hipStreamWaitEvent(c->stream, l.pass_done, 0));
@@ -1065,8 +1167,10 @@ extern "C" int rt_render(rt_ctx* c, uint32_t n_samples) {
 
 extern "C" int rt_sync(rt_ctx* c) {
     if (!c) return RT_ERR_INVALID;
+    const bool must_wait = c->lanes_must_wait;
     int rc;
-    if ((rc = bind_device(c)) != RT_OK) return rc;
+    if ((rc = bind_device_keep_graphs(c)) != RT_OK) return rc;
+    c->lanes_must_wait = must_wait;                              // waiting queues nothing
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return RT_OK;
 }
@@ -1076,7 +1180,7 @@ extern "C" int rt_poll(rt_ctx* c, int* done) {
     if (!done) return fail(c, RT_ERR_INVALID, "rt_poll: null output");
     const bool must_wait = c->lanes_must_wait;
     int rc;
-    if ((rc = bind_device(c)) != RT_OK) return rc;
+    if ((rc = bind_device_keep_graphs(c)) != RT_OK) return rc;
     c->lanes_must_wait = must_wait;                              // asking queues nothing
     const hipError_t e = hipStreamQuery(c->stream);              // every pass is followed by its accumulation on the main stream
     if (e != hipSuccess && e != hipErrorNotReady) HIPCHK(c, e);
@@ -1091,7 +1195,7 @@ extern "C" int rt_read_sum_f32(rt_ctx* c, float* rgba, size_t n_floats) {
     if (!c) return RT_ERR_INVALID;
     if (!rgba || n_floats < size_t(c->npix) * 4) return fail(c, RT_ERR_INVALID, "rt_read_sum_f32: buffer too small");
     int rc;
-    if ((rc = bind_device(c)) != RT_OK) return rc;
+    if ((rc = bind_device_keep_graphs(c)) != RT_OK) return rc;
     HIPCHK(c, hipMemcpyAsync(rgba, c->sum.p, size_t(c->npix) * 16, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return RT_OK;
@@ -1120,7 +1224,7 @@ extern "C" int rt_add_sum_f32(rt_ctx* c, const float* rgba_sum, size_t n_floats)
     if (!c) return RT_ERR_INVALID;
     if (!rgba_sum || n_floats < size_t(c->npix) * 4) return fail(c, RT_ERR_INVALID, "rt_add_sum_f32: buffer too small");
     int rc;
-    if ((rc = bind_device(c)) != RT_OK) return rc;
+    if ((rc = bind_device_keep_graphs(c)) != RT_OK) return rc;
     HIPCHK(c, c->scratch.ensure(size_t(c->npix) * 16));
     HIPCHK(c, hipMemcpyAsync(c->scratch.p, rgba_sum, size_t(c->npix) * 16, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_add_sum, dim3(grid_for(c, c->npix, 8)), dim3(kBlock), 0, c->stream, c->sum.as<float4>(), c->scratch.as<float4>(), c->npix);
@@ -1141,7 +1245,7 @@ extern "C" int rt_read_framebuffer_rgba8(rt_ctx* c, uint8_t* rgba, size_t n_byte
     if (!c) return RT_ERR_INVALID;
     if (!rgba || n_bytes < size_t(c->npix) * 4) return fail(c, RT_ERR_INVALID, "rt_read_framebuffer_rgba8: buffer too small");
     int rc;
-    if ((rc = bind_device(c)) != RT_OK) return rc;
+    if ((rc = bind_device_keep_graphs(c)) != RT_OK) return rc;
     if (!(c->flags & RT_REF_RGBA8_ACCUM)) {
         hipLaunchKernelGGL(k_tonemap, dim3(grid_for(c, c->npix, 8)), dim3(kBlock), 0, c->stream, c->sum.as<float4>(), c->fb.as<uint32_t>(), c->npix);
         HIPCHK(c, hipGetLastError());
@@ -1157,7 +1261,7 @@ extern "C" int rt_last_timings(const rt_ctx* cc, rt_timings* out) {
     if (!out) return fail(c, RT_ERR_INVALID, "rt_last_timings: null output");
     if (!(c->flags & RT_KERNEL_TIMING)) return fail(c, RT_ERR_INVALID, "rt_last_timings: context created without RT_KERNEL_TIMING");
     int rc;
-    if ((rc = bind_device(c)) != RT_OK) return rc;
+    if ((rc = bind_device_keep_graphs(c)) != RT_OK) return rc;
     if ((rc = resolve_timings(c)) != RT_OK) return rc;
     *out = c->last;
     return RT_OK;
@@ -1167,7 +1271,7 @@ extern "C" int rt_get_counters(rt_ctx* c, rt_counters* out) {
     if (!c) return RT_ERR_INVALID;
     if (!out) return fail(c, RT_ERR_INVALID, "rt_get_counters: null output");
     int rc;
-    if ((rc = bind_device(c)) != RT_OK) return rc;
+    if ((rc = bind_device_keep_graphs(c)) != RT_OK) return rc;
     TraceStats s;
     HIPCHK(c, hipMemcpyAsync(&s, c->stats.p, sizeof(s), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1181,7 +1285,7 @@ extern "C" int rt_get_counters(rt_ctx* c, rt_counters* out) {
 extern "C" int rt_reset_counters(rt_ctx* c) {
     if (!c) return RT_ERR_INVALID;
     int rc;
-    if ((rc = bind_device(c)) != RT_OK) return rc;
+    if ((rc = bind_device_keep_graphs(c)) != RT_OK) return rc;
     HIPCHK(c, hipMemsetAsync(c->stats.p, 0, sizeof(TraceStats), c->stream));
     return RT_OK;
 }

@@ -737,10 +737,10 @@ __global__ void k_finish_pass(const uint32_t* __restrict__ shard_counts, uint32_
         s += shard_counts[(b * 2 * kQueueShards + kQueueShards + threadIdx.x) * kCounterStride];
     }
     for (int off = 32; off > 0; off >>= 1) { e += __shfl_down(e, off); s += __shfl_down(s, off); }
-    if (threadIdx.x == 0) {
-        stats->extend_rays += e + camera_rays;
-        stats->shadow_rays += s;
-        stats->camera_rays += camera_rays;
+    if (threadIdx.x == 0) {                 // atomics: the per-path kernel of a pass on another lane may be adding to the same totals
+        atomicAdd(&stats->extend_rays, e + camera_rays);
+        atomicAdd(&stats->shadow_rays, s);
+        atomicAdd(&stats->camera_rays, (unsigned long long)camera_rays);
     }
 }
 

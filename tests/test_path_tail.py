@@ -100,3 +100,37 @@ def test_tail_is_not_offered_where_it_does_not_apply(rt, scene_cache):
     for flags in (rt.api.RT_EXACT_ORDER, rt.api.RT_KERNEL_TIMING, rt.api.RT_COUNT_TRAVERSAL):
         _, c = render(rt, sc, tail_max=1 << 20, tail_from=1, flags=flags)
         assert c["tail_paths"] == 0
+
+
+def test_graph_replay_of_short_passes_changes_nothing(rt, scene_cache):
+    """RT_HIP_GRAPH=1: a short pass is captured into a HIP graph the first time and replayed afterwards, with the first frame
+    index patched into the ray-generation node. Same image and counters as direct launches, over calls of different sizes, a
+    camera move (which invalidates the captured graphs) and a reset."""
+    sc = scene_cache("lit_room", width=256, height=144)
+
+    def run(graph):
+        with env(RT_HIP_GRAPH=graph):
+            r = rt.HipRenderer.create(sc, max_bounces=6, frames_per_pass=2)
+        out = []
+        for n in (1, 1, 2, 5, 1):
+            r.dispatch_compute(n)
+        r.frame_complete()
+        out.append(r.read_sum())
+        cam = np.array(sc.camera, copy=True)
+        cam["location"][0][0] += 0.25
+        r.set_camera(cam)
+        for n in (3, 1, 1):
+            r.render(n)
+        out.append(r.read_sum())
+        r.reset_accumulator()
+        r.render(4)
+        out.append(r.read_sum())
+        cnt = r.counters()
+        r.destroy()
+        return out, cnt
+
+    direct, c0 = run(0)
+    replayed, c1 = run(1)
+    for a, b in zip(direct, replayed):
+        assert np.array_equal(a, b)
+    assert c0["extend_rays"] == c1["extend_rays"] and c0["shadow_rays"] == c1["shadow_rays"] and c0["camera_rays"] == c1["camera_rays"]
