@@ -63,8 +63,8 @@ struct DevBuf {
 // RT_HIP_TRACE_BLOCKS / RT_HIP_SHADE_BLOCKS override them for tuning runs (read once per context, at creation).
 constexpr uint32_t kDefaultTraceBlocksPerCu = RT_TRACE_WAVES_PER_EU;
 constexpr uint32_t kDefaultShadeBlocksPerCu = 8;
-constexpr float kCheapSlotNs = 1.0f;   // long passes cheaper than this per path (open scenes, tiny scenes) alternate between lanes too:
-                                       // measured 0.47-0.78 ns per path on the car, glass and Cornell scenes, 1.2-2.0 on the atrium and the interior
+constexpr float kCheapSlotNs = 0.7f;   // long passes cheaper than this per path (open scenes, tiny scenes) alternate between lanes too:
+                                       // measured 0.38-0.50 ns per path on the car, glass and Cornell scenes, 0.92-1.4 on the atrium and the interior
 constexpr uint64_t kOverlapConnectSlots = 12ull << 20;   // passes of up to this many paths (5 frames of 1080p) trace their shadow rays on the side stream
 constexpr uint32_t kOverlapFromBounce = 8;               // ... and in longer passes from this bounce on, where few paths are left
 constexpr uint64_t kSmallPassSlots = 24ull << 20;   // passes of up to this many paths (12 frames of 1080p) alternate between lanes
@@ -194,6 +194,7 @@ struct rt_ctx {
     bool camera_within_limit = true;          // the camera sits where the compressed tree's boxes are conservative (SceneDev::origin_limit)
     bool lanes_must_wait = true;              // something other than rt_render has used the main stream since the last pass was queued
     float ns_per_slot = 0.0f;                 // device time per path of the last pass that ran alone; 0 = not measured yet
+    float cheap_slot_ns = kCheapSlotNs;       // long passes cheaper than this per path are cut in two and share the machine
     bool second_lane_for_short_passes = false; // lanes beyond the first take passes of at most kSmallPassSlots paths only
     bool overlap_connect = true;              // RT_HIP_OVERLAP_CONNECT=0 keeps every launch of a pass on one stream
     bool paths_ok = false;                    // path buffers match W x H (false after a resize that ran out of memory)
@@ -674,6 +675,7 @@ extern "C" int rt_create(const rt_config* cfg, rt_ctx** out) {
     if (const char* env = std::getenv("RT_HIP_TAIL_MAX")) c->tail_max_paths = uint32_t(std::max(0, std::atoi(env)));
     if (const char* env = std::getenv("RT_HIP_TAIL_SLOTS")) c->tail_pass_slots = uint32_t(std::max(0, std::atoi(env)));
     if (const char* env = std::getenv("RT_HIP_GRAPH")) c->use_graphs = std::atoi(env) != 0;
+    if (const char* env = std::getenv("RT_HIP_CHEAP_NS")) c->cheap_slot_ns = float(std::atof(env));   // tuning aid: 0 = long passes never share the machine
     if (const char* env = std::getenv("RT_HIP_LANES")) {   // tuning aid: 1..4 concurrent passes
         int v = std::atoi(env);
         if (v >= 1 && v <= int(kMaxLanes) && !(c->flags & (RT_SINGLE_STREAM | RT_KERNEL_TIMING | RT_REF_RGBA8_ACCUM))) { c->n_lanes = uint32_t(v); c->second_lane_for_short_passes = false; }
@@ -1095,11 +1097,11 @@ extern "C" int rt_render(rt_ctx* c, uint32_t n_samples) {
     // buffers hold (fewer, longer launches: less time in the ramp-down of each persistent traversal grid), short passes
     // alternate between lanes and overlap. With a fixed lane count (RT_HIP_LANES) every call is split into at least one
     // pass per lane.
-    // How a long pass is scheduled depends on what a path costs here. Every traversal launch ends with a few waves walking
-    // its longest rays at memory latency (0.2-0.3 ms whatever the list size); where paths are cheap (open scenes whose paths
-    // leave early, tiny scenes) that run-down is a large share of the pass and a second concurrent pass fills it (+10 % on the
-    // 448k-triangle car under a sky, +7 % on the Cornell box at 1080p), where they are expensive it only evicts the first
-    // pass's tree from the caches (-4 % on the atrium). The device time of the last pass that ran alone decides.
+    // How the long passes of a call are scheduled depends on what a path costs here. Every traversal launch ends with a few
+    // waves walking its longest rays at memory latency; where paths are cheap (open scenes whose paths leave early, tiny
+    // scenes) that run-down is a larger share of the pass and the call's next pass, on the other lane, fills it (64 samples
+    // per call at 1080p: glass +3.4 %, Cornell box +1.5 %, car -2.5 %), where they are expensive it only evicts the first
+    // pass's tree from the caches (-6 % on the atrium). The device time of the last pass that ran alone decides.
     for (uint32_t i = 0; i < c->n_lanes; ++i) {
         Lane& l = c->lanes[i];
         if (!l.timed || hipEventQuery(l.t_end) != hipSuccess) continue;
@@ -1108,11 +1110,13 @@ extern "C" int rt_render(rt_ctx* c, uint32_t n_samples) {
         l.timed = false;
     }
     (void)hipGetLastError();                                     // a pass still running reports "not ready": not an error
-    const bool cheap_paths = c->ns_per_slot > 0.0f && c->ns_per_slot < kCheapSlotNs;
+    const bool cheap_paths = c->ns_per_slot > 0.0f && c->ns_per_slot < c->cheap_slot_ns;
     const bool always_alternate = !c->second_lane_for_short_passes || (cheap_paths && c->n_lanes > 1);
     // a long call is cut into one pass per lane that takes long passes (two, unless RT_HIP_LANES fixes the lanes), no more
     const uint32_t long_pass_lanes = c->second_lane_for_short_passes ? std::min(c->n_lanes, kFullLanes) : c->n_lanes;
-    const uint32_t min_passes = always_alternate ? std::min<uint32_t>(long_pass_lanes, n_samples) : 1u;
+    // (cheap paths: the passes a call has anyway go to alternating lanes, but a call that fits one pass stays one pass: two
+    // 10-frame passes side by side measured 6-7 % slower than one 20-frame pass on the car and the glass scene)
+    const uint32_t min_passes = !c->second_lane_for_short_passes ? std::min<uint32_t>(long_pass_lanes, n_samples) : 1u;
     if (c->npix_pass() > c->slot_cap) return fail(c, RT_ERR_UNSUPPORTED, "rt_render: the image is too small for the tile slice that is set");
     // a tile slice has fewer pixels per frame than the path buffers were sized for: more frames fit a pass
     uint32_t fpp = c->fpp;

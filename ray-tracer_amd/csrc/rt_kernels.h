@@ -295,11 +295,7 @@ template <bool COUNT, bool ANYHIT, int TREE, class Work>
 RT_DEV void trace_persistent(const SceneDev& sc, const Work& work, uint32_t n, uint32_t* cursor, lds_u32* stack, lds_u8* slot_owner,
                              const HotNodes& hot, uint32_t& n_node, uint32_t& n_leaf, uint32_t& n_tri, uint32_t* visits = nullptr) {
     constexpr uint32_t kRefillAt = RT_REFILL_AT;     // refill once this many lanes sit idle
-    // consecutive work items a wave owns at a time: RT_CHUNK when there is plenty of work, down to 64 when the queue is
-    // short (late bounces), so every resident wave still gets a share
     const uint32_t waves_total = (gridDim.x * kTraceBlock) >> 6;
-    uint32_t kChunk = ((n / waves_total) + 63u) & ~63u;
-    kChunk = kChunk < 64u ? 64u : (kChunk > RT_CHUNK ? RT_CHUNK : kChunk);
     constexpr uint32_t kLeafBatch = RT_LEAF_BATCH;   // intersect parked leaves once this many lanes wait on one
     static_assert(TREE != kTreeWide || ANYHIT, "the uncompressed 4-wide tree serves order-independent queries only");
     constexpr bool WIDE = TREE != kTreeBinary;
@@ -313,23 +309,36 @@ RT_DEV void trace_persistent(const SceneDev& sc, const Work& work, uint32_t n, u
     const uint32_t lane = lane_id();
     // Work is handed out in chunks of consecutive items (neighbouring pixels / queue entries): a wave refills its idle
     // lanes from its current chunk, so the rays it holds stay spatially close. The first part of the list is dealt out
-    // statically (chunk k goes to wave k mod #waves: no shared counter); the last 1/2^RT_TAIL_SHIFT of it is handed out
+    // statically (chunk k goes to wave k mod #waves: no shared counter); the last RT_TAIL_EIGHTHS/8 of it is handed out
     // through the device-wide cursor in small chunks, so waves that finish their share early take over work from slow
     // ones and the grid runs down together. Without a cursor the whole list is static.
     uint32_t chunk_pos = 0, chunk_end = 0;                                   // wave-uniform
     // readfirstlane: the compiler cannot prove these wave-uniform by itself, and as scalars the whole work-distribution state
     // (chunk, static share, cursor segment, run cache) stays out of the vector registers the traversal needs
-    const uint32_t wave_id = __builtin_amdgcn_readfirstlane((blockIdx.x * kTraceBlock + threadIdx.x) >> 6);
+    // Waves are numbered across the workgroups first (wave w of workgroup b is b + w * #workgroups), so a list shorter than
+    // the grid is spread over all compute units instead of filling the first ones.
+    const uint32_t wave_id = RT_WAVE_INTERLEAVE ? __builtin_amdgcn_readfirstlane(blockIdx.x + (threadIdx.x >> 6) * gridDim.x)
+                                                : __builtin_amdgcn_readfirstlane((blockIdx.x * kTraceBlock + threadIdx.x) >> 6);
+    constexpr uint32_t kTailChunk = ANYHIT ? RT_TAIL_CHUNK_ANYHIT : RT_TAIL_CHUNK;
+    constexpr uint32_t kTailEighths = ANYHIT ? RT_TAIL_EIGHTHS_ANYHIT : RT_TAIL_EIGHTHS;
+    // The static share is at least one 64-item chunk per wave: below that the cursor could not balance anything (a wave's
+    // grain is one chunk) and every wave of the grid would queue up at it for nothing, about 90 atomics per microsecond.
+    // The static chunk is the static share dealt evenly, between 64 and RT_CHUNK items.
+    uint32_t static_target = cursor ? n - ((n >> 3) * kTailEighths) : n;
+    if (RT_STATIC_FLOOR && static_target < waves_total * 64u) static_target = n < waves_total * 64u ? n : waves_total * 64u;
+    uint32_t kChunk = (((RT_STATIC_FLOOR ? static_target : n) / waves_total) + 63u) & ~63u;
+    kChunk = kChunk < 64u ? 64u : (kChunk > RT_CHUNK ? RT_CHUNK : kChunk);
+    const uint32_t n_static = static_target == n ? n : (static_target / kChunk) * kChunk;
+    if (n_static == n) cursor = nullptr;
     uint32_t next_static = wave_id * kChunk;
-    const uint32_t static_stride = (gridDim.x * kTraceBlock >> 6) * kChunk;
-    const uint32_t n_static = cursor ? ((n - (n >> RT_TAIL_SHIFT)) / kChunk) * kChunk : n;
+    const uint32_t static_stride = waves_total * kChunk;
     bool static_done = false;
     // The dynamic part [n_static, n) can be cut into kTailCursors segments, each with a cursor of its own in its own 256-byte
     // block (a wave starts at segment (wave mod kTailCursors) and moves on when a segment is used up). Returning atomics on
     // one address are served one at a time, about 90 per microsecond on this chip, and a 20-frame launch asks for nearly
     // that while it runs down; measured, though, 8 or 16 cursors make extend 2 % faster on its own and the whole frame 4 %
     // slower when extend and connect overlap (5315 vs 5110 Mrays/s, four alternating runs each), so the default is one.
-    const uint32_t seg_len = cursor ? (((n - n_static) + kTailCursors * RT_TAIL_CHUNK - 1u) / (kTailCursors * RT_TAIL_CHUNK)) * RT_TAIL_CHUNK : 0u;
+    const uint32_t seg_len = cursor ? (((n - n_static) + kTailCursors * kTailChunk - 1u) / (kTailCursors * kTailChunk)) * kTailChunk : 0u;
     uint32_t seg = wave_id % kTailCursors, segs_empty = 0;
     uint32_t run_lo = 1u, run_hi = 0u, run_base = 0u;                        // wave-uniform: where the items around chunk_pos live (empty at first)
     // Postponed leaves (closest-hit queries on the compressed tree only; RT_SPECULATE): see phase A
@@ -350,13 +359,13 @@ RT_DEV void trace_persistent(const SceneDev& sc, const Work& work, uint32_t n, u
                     chunk_pos = chunk_end = 0;
                     while (cursor && segs_empty < kTailCursors) {
                         uint32_t off = seg_len;
-                        if (lane == 0) off = atomicAdd(cursor + seg * kCounterStride, uint32_t(RT_TAIL_CHUNK));
+                        if (lane == 0) off = atomicAdd(cursor + seg * kCounterStride, kTailChunk);
                         off = __builtin_amdgcn_readfirstlane(off);
                         const uint32_t seg_begin = n_static + seg * seg_len;
                         const uint32_t seg_end = seg_begin + seg_len < n ? seg_begin + seg_len : n;
                         if (off < seg_len && seg_begin + off < seg_end) {
                             chunk_pos = seg_begin + off;
-                            chunk_end = chunk_pos + RT_TAIL_CHUNK < seg_end ? chunk_pos + RT_TAIL_CHUNK : seg_end;
+                            chunk_end = chunk_pos + kTailChunk < seg_end ? chunk_pos + kTailChunk : seg_end;
                             segs_empty = 0;
                             break;
                         }

@@ -27,11 +27,23 @@ constexpr uint32_t kTraceBlock = RT_TRACE_BLOCK;   // workgroup size of the trav
 #ifndef RT_CHUNK
 #define RT_CHUNK 256
 #endif
-#ifndef RT_TAIL_SHIFT
-#define RT_TAIL_SHIFT 2
+#ifndef RT_TAIL_EIGHTHS
+#define RT_TAIL_EIGHTHS 4
 #endif
 #ifndef RT_TAIL_CHUNK
-#define RT_TAIL_CHUNK 64
+#define RT_TAIL_CHUNK 128
+#endif
+#ifndef RT_TAIL_EIGHTHS_ANYHIT
+#define RT_TAIL_EIGHTHS_ANYHIT RT_TAIL_EIGHTHS
+#endif
+#ifndef RT_TAIL_CHUNK_ANYHIT
+#define RT_TAIL_CHUNK_ANYHIT RT_TAIL_CHUNK
+#endif
+#ifndef RT_WAVE_INTERLEAVE
+#define RT_WAVE_INTERLEAVE 0
+#endif
+#ifndef RT_STATIC_FLOOR
+#define RT_STATIC_FLOOR 1
 #endif
 #ifndef RT_TAIL_CURSORS
 #define RT_TAIL_CURSORS 1
