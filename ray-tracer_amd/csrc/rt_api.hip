@@ -197,6 +197,7 @@ struct rt_ctx {
     float cheap_slot_ns = kCheapSlotNs;       // long passes cheaper than this per path are cut in two and share the machine
     bool second_lane_for_short_passes = false; // lanes beyond the first take passes of at most kSmallPassSlots paths only
     bool overlap_connect = true;              // RT_HIP_OVERLAP_CONNECT=0 keeps every launch of a pass on one stream
+    uint64_t overlap_slots = kOverlapConnectSlots;   // RT_HIP_OVERLAP_SLOTS: largest pass whose shadow rays all go to the side stream
     bool paths_ok = false;                    // path buffers match W x H (false after a resize that ran out of memory)
     int n_cu = 256;
     uint32_t trace_blocks_per_cu = kDefaultTraceBlocksPerCu, shade_blocks_per_cu = kDefaultShadeBlocksPerCu;
@@ -464,7 +465,7 @@ int run_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t frames, uint32_t frame
     // `side_stream_ok`: no other lane has a pass in flight. When one has, that pass fills this one's run-downs already, and the
     // side stream, which is the next lane's stream, is not free.
     const bool may_overlap = side_stream_ok && c->overlap_connect && st == l.stream && l.side != nullptr && !(c->flags & (RT_KERNEL_TIMING | RT_SINGLE_STREAM));
-    const bool overlap_all = may_overlap && uint64_t(n_slots) <= kOverlapConnectSlots;
+    const bool overlap_all = may_overlap && uint64_t(n_slots) <= c->overlap_slots;
     bool connect_pending = false;
     const bool lds_tables = c->sd.n_mat <= kLdsMats && c->sd.n_emissive <= kLdsLights;
     // the per-path kernel walks the compressed tree only, keeps no traversal counters and is not timed as a stage
@@ -671,6 +672,7 @@ extern "C" int rt_create(const rt_config* cfg, rt_ctx** out) {
     if (const char* env = std::getenv("RT_HIP_TRACE_BLOCKS")) c->trace_blocks_per_cu = uint32_t(std::max(1, std::atoi(env)));
     if (const char* env = std::getenv("RT_HIP_SHADE_BLOCKS")) c->shade_blocks_per_cu = uint32_t(std::max(1, std::atoi(env)));
     if (const char* env = std::getenv("RT_HIP_OVERLAP_CONNECT")) c->overlap_connect = std::atoi(env) != 0;
+    if (const char* env = std::getenv("RT_HIP_OVERLAP_SLOTS")) c->overlap_slots = uint64_t(std::max(0ll, std::atoll(env)));   // tuning aid
     if (const char* env = std::getenv("RT_HIP_TAIL_FROM")) c->tail_from = uint32_t(std::max(1, std::atoi(env)));
     if (const char* env = std::getenv("RT_HIP_TAIL_MAX")) c->tail_max_paths = uint32_t(std::max(0, std::atoi(env)));
     if (const char* env = std::getenv("RT_HIP_TAIL_SLOTS")) c->tail_pass_slots = uint32_t(std::max(0, std::atoi(env)));

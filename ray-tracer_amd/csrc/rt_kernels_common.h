@@ -45,6 +45,12 @@ constexpr uint32_t kTraceBlock = RT_TRACE_BLOCK;   // workgroup size of the trav
 #ifndef RT_STATIC_FLOOR
 #define RT_STATIC_FLOOR 1
 #endif
+#ifndef RT_REFILL_AT_ANYHIT
+#define RT_REFILL_AT_ANYHIT RT_REFILL_AT
+#endif
+#ifndef RT_LEAF_BATCH_ANYHIT
+#define RT_LEAF_BATCH_ANYHIT 32
+#endif
 #ifndef RT_TAIL_CURSORS
 #define RT_TAIL_CURSORS 1
 #endif
