@@ -1,6 +1,6 @@
 #!/bin/bash
 # Copies what tools/profile_r3.sh left under gpurun_out/prof_r3a (atrium) and gpurun_out/prof_r3i (interior) to the names
-# bench.py and DESIGN.md use under profiles/.
+# bench.py reads under profiles/.
 set -e
 P=gpurun_out/prof_r3a
 cp $P/roofline_counters.json profiles/r3_roofline_counters.json
