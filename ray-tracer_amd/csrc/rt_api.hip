@@ -67,6 +67,11 @@ constexpr float kCheapSlotNs = 0.7f;   // long passes cheaper than this per path
                                        // measured 0.38-0.50 ns per path on the car, glass and Cornell scenes, 0.92-1.4 on the atrium and the interior
 constexpr uint64_t kOverlapConnectSlots = 12ull << 20;   // passes of up to this many paths (5 frames of 1080p) trace their shadow rays on the side stream
 constexpr uint32_t kOverlapFromBounce = 8;               // ... and in longer passes from this bounce on, where few paths are left
+constexpr uint64_t kGraphPassSlots = kOverlapConnectSlots;   // largest pass that can be replayed from a captured HIP graph (RT_HIP_GRAPH=1)
+// ... and the largest that is by default: replay halves the host's time to queue a pass (0.10 -> 0.05 ms), which a host
+// that waits for every sample sees on small images (one sample per call: 256x256 Cornell box 0.363 -> 0.32 ms, 320x180
+// atrium 1.33 -> 1.20, 640x360 1.83 -> 1.70, 1280x720 2.98 -> 2.87, 1920x1080 4.19 -> 4.16) and nobody else
+constexpr uint64_t kGraphDefaultSlots = 1ull << 20;
 constexpr uint64_t kSmallPassSlots = 24ull << 20;   // passes of up to this many paths (12 frames of 1080p) alternate between lanes
 
 // The per-path kernel (k_path_tail) is offered the queue of every bounce from kDefaultTailFrom on, in passes of at most
@@ -202,7 +207,8 @@ struct rt_ctx {
     int n_cu = 256;
     uint32_t trace_blocks_per_cu = kDefaultTraceBlocksPerCu, shade_blocks_per_cu = kDefaultShadeBlocksPerCu;
     uint32_t tail_from = kDefaultTailFrom, tail_max_paths = kDefaultTailMaxPaths, tail_pass_slots = kDefaultTailPassSlots;
-    bool use_graphs = false;                  // short passes are replayed from captured HIP graphs (RT_HIP_GRAPH)
+    bool use_graphs = true;                   // passes of up to graph_slots paths are replayed from captured HIP graphs
+    uint64_t graph_slots = kGraphDefaultSlots; // RT_HIP_GRAPH=0: none, =1: every pass whose shadow rays may use the side stream
     uint64_t graph_epoch = 1;                 // bumped by every entry point that may change what a pass's kernels are given
 
     // scene
@@ -541,11 +547,10 @@ int finish_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t n_slots) {
 // and 4-26 % of the device time between kernels; replayed, it is one launch. Everything a pass's kernels are given is fixed
 // while scene, camera, sizes and slices stay as they are (graph_epoch) except the first frame index, a kernel argument of the
 // ray-generation node that is updated before every replay.
-constexpr uint64_t kGraphPassSlots = kOverlapConnectSlots;
 int queue_pass(rt_ctx* c, Lane& l, uint32_t frames, uint32_t frame_first, bool side_ok) {
     const uint32_t npix = c->npix_pass();
     const uint64_t n_slots = uint64_t(frames) * npix;
-    if (!c->use_graphs || n_slots == 0 || n_slots > kGraphPassSlots || (c->flags & (RT_KERNEL_TIMING | RT_COUNT_TRAVERSAL | RT_SINGLE_STREAM)))
+    if (!c->use_graphs || n_slots == 0 || n_slots > c->graph_slots || (c->flags & (RT_KERNEL_TIMING | RT_COUNT_TRAVERSAL | RT_SINGLE_STREAM)))
         return run_pass(c, l, l.stream, frames, frame_first, c->slice_stride, nullptr, side_ok);
     Lane::PassGraph* g = nullptr;
     for (Lane::PassGraph& k : l.graphs)
@@ -676,7 +681,7 @@ extern "C" int rt_create(const rt_config* cfg, rt_ctx** out) {
     if (const char* env = std::getenv("RT_HIP_TAIL_FROM")) c->tail_from = uint32_t(std::max(1, std::atoi(env)));
     if (const char* env = std::getenv("RT_HIP_TAIL_MAX")) c->tail_max_paths = uint32_t(std::max(0, std::atoi(env)));
     if (const char* env = std::getenv("RT_HIP_TAIL_SLOTS")) c->tail_pass_slots = uint32_t(std::max(0, std::atoi(env)));
-    if (const char* env = std::getenv("RT_HIP_GRAPH")) c->use_graphs = std::atoi(env) != 0;
+    if (const char* env = std::getenv("RT_HIP_GRAPH")) { c->use_graphs = std::atoi(env) != 0; c->graph_slots = kGraphPassSlots; }
     if (const char* env = std::getenv("RT_HIP_CHEAP_NS")) c->cheap_slot_ns = float(std::atof(env));   // tuning aid: 0 = long passes never share the machine
     if (const char* env = std::getenv("RT_HIP_LANES")) {   // tuning aid: 1..4 concurrent passes
         int v = std::atoi(env);
@@ -695,6 +700,7 @@ extern "C" int rt_create(const rt_config* cfg, rt_ctx** out) {
             for (int b = 0; b < v; ++b) cu_mask[b >> 5] |= 1u << (b & 31);
             c->n_cu = v;
             masked = true;
+            c->use_graphs = false;      // a replayed graph's kernel nodes need not run under the capturing stream's CU mask
         }
     }
     // Every stream of a confined context carries the mask, the main stream (accumulate, clears, copies) included: a process
