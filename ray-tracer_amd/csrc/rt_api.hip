@@ -118,6 +118,7 @@ struct Lane {
                        uint64_t epoch = 0; uint32_t frames = 0; bool side_ok = false; };
     PassGraph graphs[4];
     uint32_t next_graph = 0;
+    uint64_t seen_epoch = 0; uint32_t seen_frames = 0; bool seen_side_ok = false;   // the last shape that was queued directly
     void drop_graphs() {
         for (PassGraph& g : graphs) {
             if (g.exec) (void)hipGraphExecDestroy(g.exec);
@@ -542,8 +543,8 @@ int finish_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t n_slots) {
     return RT_OK;
 }
 
-// Queues one pass on its lane's stream: directly, or, for short passes, as a HIP graph captured from the first such pass and
-// replayed afterwards. A one-sample pass is 26 kernel launches, two dozen event operations and a memset, 0.38 ms of host time
+// Queues one pass on its lane's stream: directly, or, for short passes, as a HIP graph captured from the second such pass in a
+// row and replayed afterwards. A one-sample pass is 26 kernel launches, two dozen event operations and a memset, 0.38 ms of host time
 // and 4-26 % of the device time between kernels; replayed, it is one launch. Everything a pass's kernels are given is fixed
 // while scene, camera, sizes and slices stay as they are (graph_epoch) except the first frame index, a kernel argument of the
 // ray-generation node that is updated before every replay.
@@ -556,6 +557,11 @@ int queue_pass(rt_ctx* c, Lane& l, uint32_t frames, uint32_t frame_first, bool s
     for (Lane::PassGraph& k : l.graphs)
         if (k.exec && k.epoch == c->graph_epoch && k.frames == frames && k.side_ok == side_ok) g = &k;
     if (!g) {
+        // capture a shape the second time it comes by: capture and instantiation cost about as much as four direct passes, which a
+        // call size that is used once would never get back
+        const bool seen = l.seen_epoch == c->graph_epoch && l.seen_frames == frames && l.seen_side_ok == side_ok;
+        l.seen_epoch = c->graph_epoch; l.seen_frames = frames; l.seen_side_ok = side_ok;
+        if (!seen) return run_pass(c, l, l.stream, frames, frame_first, c->slice_stride, nullptr, side_ok);
         g = &l.graphs[l.next_graph];
         l.next_graph = (l.next_graph + 1) % (sizeof(l.graphs) / sizeof(l.graphs[0]));
         if (g->exec) (void)hipGraphExecDestroy(g->exec);

@@ -103,27 +103,29 @@ def test_tail_is_not_offered_where_it_does_not_apply(rt, scene_cache):
 
 
 def test_graph_replay_of_short_passes_changes_nothing(rt, scene_cache):
-    """RT_HIP_GRAPH=1: a short pass is captured into a HIP graph the first time and replayed afterwards, with the first frame
-    index patched into the ray-generation node. Same image and counters as direct launches, over calls of different sizes, a
-    camera move (which invalidates the captured graphs) and a reset."""
+    """RT_HIP_GRAPH=1: a lane captures a short pass into a HIP graph the second time in a row it is given that shape and replays
+    it afterwards, with the first frame index patched into the ray-generation node. Same image and counters as direct launches
+    (RT_HIP_GRAPH=0), over runs of equal calls long enough for every lane to replay, calls of other sizes in between, a camera
+    move (which invalidates the captured graphs) and a reset."""
     sc = scene_cache("lit_room", width=256, height=144)
 
     def run(graph):
         with env(RT_HIP_GRAPH=graph):
             r = rt.HipRenderer.create(sc, max_bounces=6, frames_per_pass=2)
         out = []
-        for n in (1, 1, 2, 5, 1):
+        for n in (1,) * 10 + (2, 5, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2):
             r.dispatch_compute(n)
         r.frame_complete()
         out.append(r.read_sum())
         cam = np.array(sc.camera, copy=True)
         cam["location"][0][0] += 0.25
         r.set_camera(cam)
-        for n in (3, 1, 1):
+        for n in (3,) + (1,) * 9:
             r.render(n)
         out.append(r.read_sum())
         r.reset_accumulator()
-        r.render(4)
+        for _ in range(7):
+            r.render(4)
         out.append(r.read_sum())
         cnt = r.counters()
         r.destroy()
