@@ -62,6 +62,7 @@ struct DevBuf {
 // nothing). Over all configurations 8/CU is 2-8 % of the frame; one sample per call does not care.
 // RT_HIP_TRACE_BLOCKS / RT_HIP_SHADE_BLOCKS override them for tuning runs (read once per context, at creation).
 constexpr uint32_t kDefaultTraceBlocksPerCu = RT_TRACE_WAVES_PER_EU;
+constexpr uint32_t kDefaultTraceBlocksShort = 4;
 constexpr uint32_t kDefaultShadeBlocksPerCu = 8;
 constexpr float kCheapSlotNs = 0.7f;   // long passes cheaper than this per path (open scenes, tiny scenes) alternate between lanes too:
                                        // measured 0.38-0.50 ns per path on the car, glass and Cornell scenes, 0.92-1.4 on the atrium and the interior
@@ -207,6 +208,7 @@ struct rt_ctx {
     bool paths_ok = false;                    // path buffers match W x H (false after a resize that ran out of memory)
     int n_cu = 256;
     uint32_t trace_blocks_per_cu = kDefaultTraceBlocksPerCu, shade_blocks_per_cu = kDefaultShadeBlocksPerCu;
+    uint32_t trace_blocks_short = kDefaultTraceBlocksShort;   // ... of passes whose launches run beside other launches (run_pass)
     uint32_t tail_from = kDefaultTailFrom, tail_max_paths = kDefaultTailMaxPaths, tail_pass_slots = kDefaultTailPassSlots;
     bool use_graphs = true;                   // passes of up to graph_slots paths are replayed from captured HIP graphs
     uint64_t graph_slots = kGraphDefaultSlots; // RT_HIP_GRAPH=0: none, =1: every pass whose shadow rays may use the side stream
@@ -461,7 +463,15 @@ int run_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t frames, uint32_t frame
         hipLaunchKernelGGL(k_raygen, dim3(grid_for(c, n_slots, 8)), dim3(kBlock), 0, st, c->cam, state[0], rad, npix, n_slots,
                            frame_first, frame_stride, seeds_out, c->tiles());
     }
-    const uint32_t trace_grid = trace_grid_for(c, n_slots, c->trace_blocks_per_cu);
+    // A pass short enough for its shadow rays to go to the side stream, in a context whose launches can run side by side at
+    // all (side stream or several lanes), gets traversal grids of ONE workgroup per compute unit: a full grid holds every
+    // wave slot and all the LDS until its last ray is done, so another traversal launch can only follow it; two half grids
+    // run beside each other. 1080p, samples per call 1 / 2 / 3 / 4 / 6: 3.92 -> 3.49, 2.91 -> 2.77, 2.63 -> 2.51, 2.44 -> 2.37,
+    // 2.28 -> 2.24 ms per sample; one sample per call queued back to back 2.95 -> 2.65 (car 1.41 -> 1.25, interior 4.60 ->
+    // 4.08, glass 1.81 -> 1.64). From 8 samples per call on the full grid wins (2.15 vs 2.69), and so it does where nothing
+    // overlaps (one lane without side stream, 4 samples per call: 2.45 vs 2.95). profiles/r3_trace_grid_by_call_size.txt
+    const bool side_by_side = !(c->flags & (RT_KERNEL_TIMING | RT_SINGLE_STREAM)) && (c->n_lanes > 1 || (c->overlap_connect && l.side != nullptr));
+    const uint32_t trace_grid = trace_grid_for(c, n_slots, side_by_side && uint64_t(n_slots) <= c->overlap_slots ? c->trace_blocks_short : c->trace_blocks_per_cu);
     const uint32_t shade_grid = grid_for(c, n_slots, c->shade_blocks_per_cu);
     // Shadow rays on the side stream only for passes on the lane's own stream, and never when launches are timed one by one.
     // ... and only for short passes: a launch of a few frames is mostly run-down, which the other grid fills (one 1080p sample per
@@ -680,7 +690,8 @@ extern "C" int rt_create(const rt_config* cfg, rt_ctx** out) {
     // fixes the number of lanes and alternates every pass (bit-identical results either way).
     c->n_lanes = (c->flags & (RT_SINGLE_STREAM | RT_KERNEL_TIMING | RT_REF_RGBA8_ACCUM)) ? 1 : kDefaultLanes;
     c->second_lane_for_short_passes = true;
-    if (const char* env = std::getenv("RT_HIP_TRACE_BLOCKS")) c->trace_blocks_per_cu = uint32_t(std::max(1, std::atoi(env)));
+    if (const char* env = std::getenv("RT_HIP_TRACE_BLOCKS")) c->trace_blocks_per_cu = c->trace_blocks_short = uint32_t(std::max(1, std::atoi(env)));
+    if (const char* env = std::getenv("RT_HIP_TRACE_BLOCKS_SHORT")) c->trace_blocks_short = uint32_t(std::max(1, std::atoi(env)));
     if (const char* env = std::getenv("RT_HIP_SHADE_BLOCKS")) c->shade_blocks_per_cu = uint32_t(std::max(1, std::atoi(env)));
     if (const char* env = std::getenv("RT_HIP_OVERLAP_CONNECT")) c->overlap_connect = std::atoi(env) != 0;
     if (const char* env = std::getenv("RT_HIP_OVERLAP_SLOTS")) c->overlap_slots = uint64_t(std::max(0ll, std::atoll(env)));   // tuning aid
