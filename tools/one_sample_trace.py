@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ray_tracer_amd as rt
 from ray_tracer_amd import api, scenes
 sc = scenes.GENERATORS["atrium"](width=1920, height=1080).finalize(spatial=True)
-os.environ["RT_HIP_LANES"] = "1"
+if os.environ.get("ONE_SAMPLE_TRACE_DEFAULT", "0") == "0":
+    os.environ["RT_HIP_LANES"] = "1"          # one lane; ONE_SAMPLE_TRACE_DEFAULT=1 traces the default stream plan instead
 r = rt.HipRenderer.create(sc, max_bounces=8, frames_per_pass=1)
 for _ in range(6):
     r.render(1); r.frame_complete()
