@@ -67,7 +67,7 @@ constexpr uint32_t kDefaultShadeBlocksPerCu = 8;
 constexpr float kCheapSlotNs = 0.7f;   // long passes cheaper than this per path (open scenes, tiny scenes) alternate between lanes too:
                                        // measured 0.38-0.50 ns per path on the car, glass and Cornell scenes, 0.92-1.4 on the atrium and the interior
 constexpr uint64_t kOverlapConnectSlots = 12ull << 20;   // passes of up to this many paths (5 frames of 1080p) trace their shadow rays on the side stream
-constexpr uint32_t kOverlapFromBounce = 8;               // ... and in longer passes from this bounce on, where few paths are left
+constexpr uint32_t kOverlapFromBounce = 4;               // ... and in longer passes from this bounce on, where few paths are left (on half-size grids)
 constexpr uint64_t kGraphPassSlots = kOverlapConnectSlots;   // largest pass that can be replayed from a captured HIP graph (RT_HIP_GRAPH=1)
 // ... and the largest that is by default: replay halves the host's time to queue a pass (0.10 -> 0.05 ms), which a host
 // that waits for every sample sees on small images (one sample per call: 256x256 Cornell box 0.363 -> 0.32 ms, 320x180
@@ -208,6 +208,7 @@ struct rt_ctx {
     bool paths_ok = false;                    // path buffers match W x H (false after a resize that ran out of memory)
     int n_cu = 256;
     uint32_t trace_blocks_per_cu = kDefaultTraceBlocksPerCu, shade_blocks_per_cu = kDefaultShadeBlocksPerCu;
+    uint32_t trace_blocks_late = kDefaultTraceBlocksShort, overlap_from = kOverlapFromBounce;   // tuning aids: RT_HIP_TRACE_BLOCKS_LATE, RT_HIP_OVERLAP_FROM
     uint32_t trace_blocks_short = kDefaultTraceBlocksShort;   // ... of passes whose launches run beside other launches (run_pass)
     uint32_t tail_from = kDefaultTailFrom, tail_max_paths = kDefaultTailMaxPaths, tail_pass_slots = kDefaultTailPassSlots;
     bool use_graphs = true;                   // passes of up to graph_slots paths are replayed from captured HIP graphs
@@ -472,13 +473,17 @@ int run_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t frames, uint32_t frame
     // overlaps (one lane without side stream, 4 samples per call: 2.45 vs 2.95). profiles/r3_trace_grid_by_call_size.txt
     const bool side_by_side = !(c->flags & (RT_KERNEL_TIMING | RT_SINGLE_STREAM)) && (c->n_lanes > 1 || (c->overlap_connect && l.side != nullptr));
     const uint32_t trace_grid = trace_grid_for(c, n_slots, side_by_side && uint64_t(n_slots) <= c->overlap_slots ? c->trace_blocks_short : c->trace_blocks_per_cu);
+    const uint32_t late_grid = trace_grid_for(c, n_slots, c->trace_blocks_late);   // launches of a long pass that overlap (see below)
     const uint32_t shade_grid = grid_for(c, n_slots, c->shade_blocks_per_cu);
     // Shadow rays on the side stream only for passes on the lane's own stream, and never when launches are timed one by one.
     // ... and only for short passes: a launch of a few frames is mostly run-down, which the other grid fills (one 1080p sample per
     // call: 4.4 instead of 5.1 ms with the host waiting, 3.4 instead of 3.8 ms queued back to back); from about eight frames
     // on the two grids only take each other's cache lines (2.43 vs 2.47 ms per sample at 8 frames, 2.23 vs 2.27 at 20).
-    // In a long pass the bounces beyond the eighth are sparse whatever the scene (a 24-bounce glass scene: 1.19 -> 1.10 ms per
-    // sample with their shadow rays on the side stream; profiles/r3_all_configs.jsonl).
+    // In a long pass the later bounces are sparse whatever the scene: from the fifth on their shadow rays go to the side stream
+    // as well, and the launches that then overlap (connect of bounce b, extend of bounce b + 1) run on half-size grids like
+    // those of a short pass. 64 samples per call, Mrays/s: 24-bounce glass 5975, 5983 -> 6295, 6146; atrium 6700, 6611 ->
+    // 6714, 6741; interior 4K 4211, 4209 -> 4223, 4242. With full grids the same overlap gained nothing from bounce 4 (6674)
+    // and cost 1-2 % from bounce 3 (6579); profiles/r3_late_bounce_overlap.txt.
     // `side_stream_ok`: no other lane has a pass in flight. When one has, that pass fills this one's run-downs already, and the
     // side stream, which is the next lane's stream, is not free.
     const bool may_overlap = side_stream_ok && c->overlap_connect && st == l.stream && l.side != nullptr && !(c->flags & (RT_KERNEL_TIMING | RT_SINGLE_STREAM));
@@ -511,7 +516,8 @@ int run_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t frames, uint32_t frame
             // camera rays may start anywhere; every later ray starts on a surface, inside the scene bounds
             const bool fast = c->fast && (b != 0 || c->camera_within_limit);
             auto kern = count ? (fast ? k_extend<true, true> : k_extend<true, false>) : (fast ? k_extend<false, true> : k_extend<false, false>);
-            hipLaunchKernelGGL(kern, dim3(trace_grid), dim3(kTraceBlock), 0, st, c->sd, in, hit, rin, RT_CURSOR(l.ext_cursor(b)), c->tstats());
+            const bool beside_connect = !overlap_all && may_overlap && b > c->overlap_from && c->sd.n_light + c->sd.n_emissive != 0;   // the previous bounce's shadow rays are on the side stream
+            hipLaunchKernelGGL(kern, dim3(beside_connect ? late_grid : trace_grid), dim3(kTraceBlock), 0, st, c->sd, in, hit, rin, RT_CURSOR(l.ext_cursor(b)), c->tstats());
         }
         // shade rewrites the light-sample queue and adds to the radiance slots the previous bounce's shadow rays still use
         if (connect_pending) { HIPCHK(c, hipStreamWaitEvent(st, l.connected, 0)); connect_pending = false; }
@@ -524,7 +530,7 @@ int run_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t frames, uint32_t frame
         }
         if (c->sd.n_light + c->sd.n_emissive != 0) {
             hipStream_t cs = st;
-            const bool overlap = overlap_all || (may_overlap && b >= kOverlapFromBounce);
+            const bool overlap = overlap_all || (may_overlap && b >= c->overlap_from);
             if (overlap) {
                 HIPCHK(c, hipEventRecord(l.shaded, st));
                 HIPCHK(c, hipStreamWaitEvent(l.side, l.shaded, 0));
@@ -536,7 +542,7 @@ int run_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t frames, uint32_t frame
                 const Regions rsh{l.shadow_counts(b), l.shard_cap, 0u};
                 auto kern = c->fast ? (count ? (any ? k_connect<true, true, true> : k_connect<true, false, true>) : (any ? k_connect<false, true, true> : k_connect<false, false, true>))
                                     : (count ? (any ? k_connect<true, true, false> : k_connect<true, false, false>) : (any ? k_connect<false, true, false> : k_connect<false, false, false>));
-                hipLaunchKernelGGL(kern, dim3(trace_grid), dim3(kTraceBlock), 0, cs, c->sd, sq, rad, rsh, RT_CURSOR(l.con_cursor(b)), c->tstats());
+                hipLaunchKernelGGL(kern, dim3(overlap && !overlap_all ? late_grid : trace_grid), dim3(kTraceBlock), 0, cs, c->sd, sq, rad, rsh, RT_CURSOR(l.con_cursor(b)), c->tstats());
             }
             if (overlap) { HIPCHK(c, hipEventRecord(l.connected, l.side)); connect_pending = true; }
         }
@@ -690,7 +696,9 @@ extern "C" int rt_create(const rt_config* cfg, rt_ctx** out) {
     // fixes the number of lanes and alternates every pass (bit-identical results either way).
     c->n_lanes = (c->flags & (RT_SINGLE_STREAM | RT_KERNEL_TIMING | RT_REF_RGBA8_ACCUM)) ? 1 : kDefaultLanes;
     c->second_lane_for_short_passes = true;
-    if (const char* env = std::getenv("RT_HIP_TRACE_BLOCKS")) c->trace_blocks_per_cu = c->trace_blocks_short = uint32_t(std::max(1, std::atoi(env)));
+    if (const char* env = std::getenv("RT_HIP_TRACE_BLOCKS")) c->trace_blocks_per_cu = c->trace_blocks_short = c->trace_blocks_late = uint32_t(std::max(1, std::atoi(env)));
+    if (const char* env = std::getenv("RT_HIP_TRACE_BLOCKS_LATE")) c->trace_blocks_late = uint32_t(std::max(1, std::atoi(env)));
+    if (const char* env = std::getenv("RT_HIP_OVERLAP_FROM")) c->overlap_from = uint32_t(std::max(0, std::atoi(env)));
     if (const char* env = std::getenv("RT_HIP_TRACE_BLOCKS_SHORT")) c->trace_blocks_short = uint32_t(std::max(1, std::atoi(env)));
     if (const char* env = std::getenv("RT_HIP_SHADE_BLOCKS")) c->shade_blocks_per_cu = uint32_t(std::max(1, std::atoi(env)));
     if (const char* env = std::getenv("RT_HIP_OVERLAP_CONNECT")) c->overlap_connect = std::atoi(env) != 0;
