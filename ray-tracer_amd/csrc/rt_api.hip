@@ -448,7 +448,7 @@ void refresh_camera(rt_ctx* c) {
 
 // One wavefront pass on lane `l`: `frames` samples of every pixel, bounce by bounce. Leaves radiance in l.rad.
 int run_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t frames, uint32_t frame_first, uint32_t frame_stride, uint32_t* seeds_out,
-             bool side_stream_ok = true) {
+             bool side_stream_ok = true, bool beside_another_long_pass = false) {
     const uint32_t npix = c->npix_pass();
     const uint32_t n_slots = frames * npix;
     if (uint64_t(n_slots) > l.slot_cap) return fail(c, RT_ERR_DEVICE, "internal: a pass larger than its lane's path buffers");
@@ -472,7 +472,11 @@ int run_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t frames, uint32_t frame
     // 4.08, glass 1.81 -> 1.64). From 8 samples per call on the full grid wins (2.15 vs 2.69), and so it does where nothing
     // overlaps (one lane without side stream, 4 samples per call: 2.45 vs 2.95). profiles/r3_trace_grid_by_call_size.txt
     const bool side_by_side = !(c->flags & (RT_KERNEL_TIMING | RT_SINGLE_STREAM)) && (c->n_lanes > 1 || (c->overlap_connect && l.side != nullptr));
-    const uint32_t trace_grid = trace_grid_for(c, n_slots, side_by_side && uint64_t(n_slots) <= c->overlap_slots ? c->trace_blocks_short : c->trace_blocks_per_cu);
+    // (A long pass that runs beside another long pass of the same call, on the other lane, gets half grids for the same reason:
+    // 64 samples per call at 1080p, one lane / two lanes with full grids / with half grids: Cornell box 10250 / 10440 / 12120
+    // Mrays/s, glass blob 7050 / 7190 / 7340, car 5820 / 5600 / 5830.)
+    const bool half_grids = (side_by_side && uint64_t(n_slots) <= c->overlap_slots) || beside_another_long_pass;
+    const uint32_t trace_grid = trace_grid_for(c, n_slots, half_grids ? c->trace_blocks_short : c->trace_blocks_per_cu);
     const uint32_t late_grid = trace_grid_for(c, n_slots, c->trace_blocks_late);   // launches of a long pass that overlap (see below)
     const uint32_t shade_grid = grid_for(c, n_slots, c->shade_blocks_per_cu);
     // Shadow rays on the side stream only for passes on the lane's own stream, and never when launches are timed one by one.
@@ -564,11 +568,11 @@ int finish_pass(rt_ctx* c, Lane& l, hipStream_t st, uint32_t n_slots) {
 // and 4-26 % of the device time between kernels; replayed, it is one launch. Everything a pass's kernels are given is fixed
 // while scene, camera, sizes and slices stay as they are (graph_epoch) except the first frame index, a kernel argument of the
 // ray-generation node that is updated before every replay.
-int queue_pass(rt_ctx* c, Lane& l, uint32_t frames, uint32_t frame_first, bool side_ok) {
+int queue_pass(rt_ctx* c, Lane& l, uint32_t frames, uint32_t frame_first, bool side_ok, bool beside_another_long_pass) {
     const uint32_t npix = c->npix_pass();
     const uint64_t n_slots = uint64_t(frames) * npix;
-    if (!c->use_graphs || n_slots == 0 || n_slots > c->graph_slots || (c->flags & (RT_KERNEL_TIMING | RT_COUNT_TRAVERSAL | RT_SINGLE_STREAM)))
-        return run_pass(c, l, l.stream, frames, frame_first, c->slice_stride, nullptr, side_ok);
+    if (!c->use_graphs || n_slots == 0 || n_slots > c->graph_slots || beside_another_long_pass || (c->flags & (RT_KERNEL_TIMING | RT_COUNT_TRAVERSAL | RT_SINGLE_STREAM)))
+        return run_pass(c, l, l.stream, frames, frame_first, c->slice_stride, nullptr, side_ok, beside_another_long_pass);
     Lane::PassGraph* g = nullptr;
     for (Lane::PassGraph& k : l.graphs)
         if (k.exec && k.epoch == c->graph_epoch && k.frames == frames && k.side_ok == side_ok) g = &k;
@@ -1157,6 +1161,9 @@ extern "C" int rt_render(rt_ctx* c, uint32_t n_samples) {
         fpp = std::max(1u, std::min(c->fpp_cfg ? c->fpp_cfg : 64u, c->slot_cap / std::max(1u, c->npix_pass())));
     uint32_t n_pass = std::max<uint32_t>((n_samples + fpp - 1) / fpp, min_passes);
     const bool single_pass_call = n_pass == 1;
+    // cheap paths: the long passes of this call run side by side on the two full-size lanes. They get half-size traversal grids
+    // (run_pass), and none of them borrows the other lane's stream for its shadow rays: the other pass is about to be queued there
+    const bool long_passes_side_by_side = c->second_lane_for_short_passes && cheap_paths && c->n_lanes > 1 && n_pass > 1;
     uint32_t left = n_samples;
     const uint32_t npix_pass = c->npix_pass(), pixels_owned = c->pixels_owned();
     while (left) {
@@ -1179,7 +1186,8 @@ extern "C" int rt_render(rt_ctx* c, uint32_t n_samples) {
         (void)hipGetLastError();
         const bool time_it = c->second_lane_for_short_passes && single_pass_call && l.t_begin != nullptr && !others_busy;
         if (time_it) HIPCHK(c, hipEventRecord(l.t_begin, l.stream));
-        if ((rc = queue_pass(c, l, frames, frame_first, !others_busy)) != RT_OK) return rc;
+        const bool beside_long = long_passes_side_by_side && !short_pass;
+        if ((rc = queue_pass(c, l, frames, frame_first, !others_busy && !beside_long, beside_long)) != RT_OK) return rc;
         if (time_it) { HIPCHK(c, hipEventRecord(l.t_end, l.stream)); l.timed = true; l.timed_slots = uint64_t(frames) * npix_pass; }
         HIPCHK(c, hipEventRecord(l.pass_done, l.stream));
         HIPCHK(c, hipStreamWaitEvent(c->stream, l.pass_done, 0));
