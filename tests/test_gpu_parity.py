@@ -789,6 +789,29 @@ def test_overlapped_passes_match_single_stream_bit_for_bit(rt, full_atrium, monk
     one.destroy(); two.destroy()
 
 
+def test_long_passes_side_by_side_match_single_stream_bit_for_bit(rt, full_atrium, monkeypatch):
+    """A call of two long passes (64 samples of 1080p = 2 x 32 frames) in a context that runs the long passes of a call side
+    by side on its two full-size lanes, on half-size traversal grids (what scenes with cheap paths get; RT_HIP_CHEAP_NS forces
+    it for the atrium): the same accumulator and the same ray counts as one stream, bit for bit. The 40-sample call that
+    follows is a single long pass whose later bounces put their shadow rays on the side stream."""
+    from ray_tracer_amd import api
+    one = rt.HipRenderer.create(full_atrium, max_bounces=8, flags=api.RT_SINGLE_STREAM)
+    monkeypatch.setenv("RT_HIP_CHEAP_NS", "10")
+    two = rt.HipRenderer.create(full_atrium, max_bounces=8)
+    monkeypatch.delenv("RT_HIP_CHEAP_NS")
+    for r in (one, two):
+        r.render(4)                                   # a pass that runs alone: the context measures what a path costs
+        r.frame_complete()
+        r.dispatch_compute(64)
+        r.dispatch_compute(20)
+        r.frame_complete()
+    assert two.sample_count() == one.sample_count() == 88
+    assert np.array_equal(one.read_sum(), two.read_sum())
+    c1, c2 = one.counters(), two.counters()
+    assert c1["extend_rays"] == c2["extend_rays"] and c1["shadow_rays"] == c2["shadow_rays"] and c1["camera_rays"] == c2["camera_rays"]
+    one.destroy(); two.destroy()
+
+
 def test_full_size_sample_slices_sum_to_the_whole(rt, full_atrium):
     """Two contexts rendering frames {0,2} and {1,3} add up to one context rendering frames 0..3 (fp32 order aside):
     the multi-GPU partition, rehearsed on one GPU, including the host-staged reduce entry point."""
